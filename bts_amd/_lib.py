@@ -1,0 +1,126 @@
+"""ctypes binding of libbts_amd.so (the C ABI declared in include/bts_amd.h).
+
+The library must share PyTorch's HIP runtime so that streams and device pointers are
+interchangeable: ``import torch`` first (it loads its bundled ``libamdhip64.so``, SONAME
+``libamdhip64.so.7``), then ``dlopen`` ours, whose DT_NEEDED entry resolves to the already
+loaded runtime.  There is NO fallback: if the library is missing or a call fails this raises.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported before the dlopen below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbts_amd.so")
+
+BTS_F32, BTS_BF16 = 0, 1
+ACT_NONE, ACT_ELU, ACT_SIGMOID, ACT_RELU = 0, 1, 2, 3
+MAX_SEG, MAX_TAP = 6, 16
+ERRORS = {-1: "BTS_ERR_ARG", -2: "BTS_ERR_LAUNCH", -3: "BTS_ERR_UNSUPPORTED"}
+
+
+class BtsAmdError(RuntimeError):
+    pass
+
+
+class Seg(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("C", C.c_int32), ("stride", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("N", C.c_int32), ("Hg", C.c_int32), ("Wg", C.c_int32),
+        ("nseg", C.c_int32), ("seg", Seg * MAX_SEG),
+        ("Hx", C.c_int32), ("Wx", C.c_int32), ("isc", C.c_int32),
+        ("nphase", C.c_int32), ("T", C.c_int32),
+        ("dy", C.c_int16 * MAX_TAP), ("dx", C.c_int16 * MAX_TAP),
+        ("ioy", C.c_int16 * MAX_TAP), ("iox", C.c_int16 * MAX_TAP),
+        ("w", C.c_void_p), ("Cout", C.c_int32),
+        ("y", C.c_void_p), ("y_dtype", C.c_int32), ("y_stride", C.c_int32),
+        ("Hy", C.c_int32), ("Wy", C.c_int32), ("osc", C.c_int32), ("act", C.c_int32),
+        ("out_scale", C.c_float), ("out_scale_n", C.c_void_p), ("accumulate", C.c_int32),
+    ]
+
+
+_i, _l, _f, _p = C.c_int, C.c_long, C.c_float, C.c_void_p
+
+# name -> argtypes (restype is int unless listed in _LONG_RET); mirrors include/bts_amd.h exactly
+SIGNATURES = {
+    "bts_abi_version": [],
+    "bts_current_device": [],
+    "bts_lpg_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "bts_lpg_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "bts_lpg_head_fwd": [_p, _i, _p, _p, _i, _i, _i, _i, _f, _p],
+    "bts_lpg_head_bwd": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "bts_pack_maps": [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "bts_unpack_maps": [_p, _i, _i, _p, _p, _i, _i, _i, _i, _p],
+    "bts_silog_workspace_bytes": [_l],
+    "bts_silog_fwd": [_p, _p, _p, _f, _l, _f, _p, _p, _p, _p],
+    "bts_silog_bwd": [_p, _p, _p, _f, _l, _f, _p, _p, _p, _p, _p],
+    "bts_conv_fwd": [C.POINTER(ConvDesc), _p],
+    "bts_conv_wgrad": [C.POINTER(ConvDesc), _p, _i, _p, _p],
+    "bts_pack_weight": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p, _p],
+    "bts_unpack_wgrad": [_p, _i, _i, _i, _p, _i, _i, _p, _p, _i, _p],
+    "bts_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "bts_nhwc_to_nchw": [_p, _i, _i, _p, _p, _i, _i, _i, _i, _p],
+    "bts_bn_stats_workspace_bytes": [_l, _i],
+    "bts_bn_stats": [_p, _i, _i, _l, _i, _p, _p, _p, _p],
+    "bts_bn_prepare": [_p, _p, _i, _l, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p],
+    "bts_affine_act": [_p, _i, _i, _p, _i, _i, _l, _i, _p, _p, _i, _p],
+    "bts_bn_bwd_reduce": [_p, _i, _p, _i, _i, _l, _i, _p, _p, _p, _p, _i, _p, _p, _p],
+    "bts_bn_bwd_apply": [_p, _i, _p, _i, _p, _i, _i, _l, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p],
+    "bts_act_bwd": [_p, _i, _i, _p, _i, _i, _p, _i, _i, _l, _i, _i, _f, _p, _l, _p],
+    "bts_add_to": [_p, _i, _i, _p, _i, _i, _l, _i, _i, _p],
+    "bts_adamw_step": [_p, _p, _p, _p, _p, _i, _l, _f, _f, _f, _f, _f, _f, _f, _p],
+}
+_LONG_RET = {"bts_silog_workspace_bytes", "bts_bn_stats_workspace_bytes"}
+_NO_CHECK = _LONG_RET | {"bts_abi_version", "bts_current_device"}
+
+_lib = None
+
+
+def load():
+    """dlopen the library (once) and attach prototypes.  Raises BtsAmdError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BtsAmdError(
+            "libbts_amd.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `python bts_amd/build.py`).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
+        fn.argtypes = args
+        fn.restype = C.c_long if name in _LONG_RET else C.c_int
+    if lib.bts_abi_version() != 1:
+        raise BtsAmdError("libbts_amd.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an entry point and raise on a non-zero status."""
+    rc = getattr(load(), name)(*args)
+    if name not in _NO_CHECK and rc != 0:
+        raise BtsAmdError("%s failed: %s (%d)" % (name, ERRORS.get(rc, "?"), rc))
+    return rc
+
+
+def stream_ptr():
+    """The current PyTorch HIP stream as a raw hipStream_t."""
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return BTS_F32
+    if dt == torch.bfloat16:
+        return BTS_BF16
+    raise BtsAmdError("unsupported activation dtype %s" % dt)
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise BtsAmdError("bts_amd kernels run on an MI355X (HIP) device only; got a %s tensor. "
+                          "There is no CPU fallback in the product path." % t.device)

@@ -1,0 +1,205 @@
+"""Host-side description of one decoder convolution for the implicit-GEMM kernels.
+
+A ``ConvLayer`` owns the static geometry of a conv of pytorch/bts.py (kernel size, dilation,
+fused nearest-x2 up-sampling, how its input channels split over the concatenated input
+tensors) and turns the PyTorch-layout f32 weight ``[Cout, Cin, kh, kw]`` into the packed
+operands of ``bts_conv_fwd`` / its data-gradient, and the packed weight-gradient back.
+
+Up-sampling convs (``upconv``, bts.py:69-80: nearest x2 then 3x3, pad 1) are evaluated as four
+2x2 sub-pixel phase convolutions on the LOW-resolution input: output pixel (2i+a, 2j+b) only
+ever sees input rows {i-1, i} (a = 0) or {i, i+1} (a = 1), with the 3x3 taps that land on the
+same low-res pixel pre-summed.  That is 16/36 of the MACs of the literal formulation and never
+materialises the up-sampled tensor.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, call, dtype_code, stream_ptr
+from .ops import pad_to, pix_stride, vec_of
+
+# row/column structure of the sub-pixel phases: phase parity -> [(low-res offset, [3x3 tap indices])]
+_PHASE = {0: [(-1, [0]), (0, [1, 2])], 1: [(0, [0, 1]), (1, [2])]}
+
+
+def _taps_plain(kk, dil):
+    if kk == 1:
+        return [(0, 0, 0, 0)], [1]
+    taps, masks = [], []
+    for ky in range(3):
+        for kx in range(3):
+            taps.append(((ky - 1) * dil, (kx - 1) * dil, 0, 0))
+            masks.append(1 << (ky * 3 + kx))
+    return taps, masks
+
+
+def _taps_up():
+    """16 (phase-major) taps of the sub-pixel decomposition: (dy, dx, a, b) and 3x3 source masks."""
+    taps, masks = [], []
+    for a in (0, 1):
+        for b in (0, 1):
+            for oy, kys in _PHASE[a]:
+                for ox, kxs in _PHASE[b]:
+                    taps.append((oy, ox, a, b))
+                    masks.append(sum(1 << (ky * 3 + kx) for ky in kys for kx in kxs))
+    return taps, masks
+
+
+class ConvLayer:
+    """Geometry + weight packing of one conv.  seg_channels: logical channels per input tensor."""
+
+    def __init__(self, name, cout, seg_channels, kk, dil=1, up=False):
+        self.name, self.cout, self.kk, self.dil, self.up = name, cout, kk, dil, up
+        self.seg_channels = list(seg_channels)
+        self.cin = sum(seg_channels)
+        if up:
+            assert kk == 9 and dil == 1
+            self.taps, self.masks = _taps_up()
+            self.nphase, self.T = 4, 4
+        else:
+            self.taps, self.masks = _taps_plain(kk, dil)
+            self.nphase, self.T = 1, len(self.taps)
+        self._cache = {}
+
+    # -- per (dtype, device) tables ----------------------------------------------------------
+    def tables(self, dtype, device):
+        key = (dtype, str(device))
+        tb = self._cache.get(key)
+        if tb is None:
+            v = vec_of(dtype)
+            pads = [pad_to(c, v) for c in self.seg_channels]
+            cmap, kinv, seg_rows = [], [], []
+            c0 = 0
+            for c, cp in zip(self.seg_channels, pads):
+                base = len(cmap)
+                cmap += list(range(c0, c0 + c)) + [-1] * (cp - c)
+                kinv += list(range(base, base + c))
+                seg_rows.append(list(range(c0, c0 + c)) + [-1] * (cp - c))
+                c0 += c
+            tb = dict(
+                v=v, pads=pads, ktot=sum(pads), cout_pad=pad_to(self.cout, v),
+                cmap=torch.tensor(cmap, dtype=torch.int32, device=device),
+                kinv=torch.tensor(kinv, dtype=torch.int32, device=device),
+                seg_rows=[torch.tensor(r, dtype=torch.int32, device=device) for r in seg_rows],
+                cmap_out=torch.tensor(list(range(self.cout)) + [-1] * (pad_to(self.cout, v) - self.cout),
+                                      dtype=torch.int32, device=device),
+                masks=(C.c_uint16 * len(self.masks))(*self.masks),
+            )
+            self._cache[key] = tb
+        return tb
+
+    # -- weight packing ------------------------------------------------------------------------
+    def pack_fwd(self, weight, dtype):
+        tb = self.tables(dtype, weight.device)
+        ttot = self.nphase * self.T
+        out = torch.empty((self.cout, ttot, tb["ktot"]), dtype=dtype, device=weight.device)
+        call("bts_pack_weight", C.c_void_p(weight.data_ptr()), self.cout, self.cin, self.kk, 0,
+             C.c_void_p(tb["cmap"].data_ptr()), self.cout, tb["ktot"], ttot, tb["masks"], dtype_code(dtype),
+             C.c_void_p(out.data_ptr()), stream_ptr())
+        return out
+
+    def pack_dgrad(self, weight, dtype, seg):
+        """Data-gradient operand for input segment `seg`: [Cseg_pad][Ttot][Cout_pad]."""
+        tb = self.tables(dtype, weight.device)
+        ttot = self.nphase * self.T
+        rows = tb["seg_rows"][seg]
+        out = torch.empty((rows.numel(), ttot, tb["cout_pad"]), dtype=dtype, device=weight.device)
+        call("bts_pack_weight", C.c_void_p(weight.data_ptr()), self.cout, self.cin, self.kk, 1,
+             C.c_void_p(rows.data_ptr()), rows.numel(), tb["cout_pad"], ttot, tb["masks"], dtype_code(dtype),
+             C.c_void_p(out.data_ptr()), stream_ptr())
+        return out
+
+    def unpack_wgrad(self, dwp, dtype):
+        tb = self.tables(dtype, dwp.device)
+        ttot = self.nphase * self.T
+        shape = (self.cout, self.cin, 3, 3) if self.kk == 9 else (self.cout, self.cin, 1, 1)
+        gw = torch.empty(shape, dtype=torch.float32, device=dwp.device)
+        call("bts_unpack_wgrad", C.c_void_p(dwp.data_ptr()), self.cout, self.cin, self.kk, C.c_void_p(tb["kinv"].data_ptr()),
+             tb["ktot"], ttot, tb["masks"], C.c_void_p(gw.data_ptr()), 0, stream_ptr())
+        return gw
+
+    # -- descriptors -----------------------------------------------------------------------------
+    def _desc(self, dtype, segs, N, Hg, Wg):
+        d = ConvDesc()
+        d.dtype = dtype_code(dtype)
+        d.N, d.Hg, d.Wg = N, Hg, Wg
+        d.nseg = len(segs)
+        for i, s in enumerate(segs):
+            d.seg[i].ptr = s.data_ptr()
+            d.seg[i].C = s.shape[3]
+            d.seg[i].stride = pix_stride(s)
+        d.Hx, d.Wx = segs[0].shape[1], segs[0].shape[2]
+        return d
+
+    def forward(self, segs, wp, out, act, out_scale=1.0, out_scale_n=None):
+        """segs: NHWC input tensors (padded channels); wp = pack_fwd(weight); out: NHWC [N,Ho,Wo,>=Cout]
+        or a single-channel f32 map [N,Ho,Wo]."""
+        dtype = segs[0].dtype
+        N, Hx, Wx, _ = segs[0].shape
+        d = self._desc(dtype, segs, N, Hx, Wx)
+        d.isc = 1
+        d.nphase, d.T = self.nphase, self.T
+        for i, (dy, dx, a, b) in enumerate(self.taps):
+            d.dy[i], d.dx[i], d.ioy[i], d.iox[i] = dy, dx, 0, 0
+        d.w = wp.data_ptr()
+        d.Cout = self.cout
+        self._set_out(d, out)
+        d.osc = 2 if self.up else 1
+        d.act = act
+        d.out_scale = out_scale
+        d.out_scale_n = out_scale_n.data_ptr() if out_scale_n is not None else None
+        d.accumulate = 0
+        call("bts_conv_fwd", C.byref(d), stream_ptr())
+        return out
+
+    @staticmethod
+    def _set_out(d, out):
+        d.y = out.data_ptr()
+        d.y_dtype = dtype_code(out.dtype)
+        if out.dim() == 3:
+            d.y_stride, d.Hy, d.Wy = 1, out.shape[1], out.shape[2]
+        else:
+            d.y_stride, d.Hy, d.Wy = pix_stride(out), out.shape[1], out.shape[2]
+
+    def dgrad(self, dz, wd, seg_index, gx, accumulate):
+        """gx (+)= data-gradient w.r.t. input segment seg_index.  dz: NHWC [N,Ho,Wo,Cout_pad]."""
+        dtype = dz.dtype
+        N = gx.shape[0]
+        Hg, Wg = gx.shape[1], gx.shape[2]
+        d = self._desc(dtype, [dz], N, Hg, Wg)
+        if self.up:
+            d.isc, d.nphase, d.T = 2, 1, 16
+            for i, (dy, dx, a, b) in enumerate(self.taps):
+                d.dy[i], d.dx[i], d.ioy[i], d.iox[i] = -dy, -dx, a, b
+        else:
+            d.isc, d.nphase, d.T = 1, 1, self.T
+            for i, (dy, dx, a, b) in enumerate(self.taps):
+                d.dy[i], d.dx[i], d.ioy[i], d.iox[i] = -dy, -dx, 0, 0
+        d.w = wd.data_ptr()
+        d.Cout = gx.shape[3]
+        self._set_out(d, gx)
+        d.osc = 1
+        d.act = _lib.ACT_NONE
+        d.out_scale = 1.0
+        d.out_scale_n = None
+        d.accumulate = int(accumulate)
+        call("bts_conv_fwd", C.byref(d), stream_ptr())
+        return gx
+
+    def wgrad(self, segs, dz):
+        """Returns the f32 weight gradient in PyTorch layout."""
+        dtype = segs[0].dtype
+        N, Hx, Wx, _ = segs[0].shape
+        tb = self.tables(dtype, dz.device)
+        d = self._desc(dtype, segs, N, Hx, Wx)
+        d.isc = 1
+        d.nphase, d.T = self.nphase, self.T
+        for i, (dy, dx, a, b) in enumerate(self.taps):
+            d.dy[i], d.dx[i], d.ioy[i], d.iox[i] = dy, dx, 0, 0
+        d.Cout = self.cout
+        d.Hy, d.Wy = dz.shape[1], dz.shape[2]
+        d.osc = 2 if self.up else 1
+        dwp = torch.zeros((self.cout, self.nphase * self.T, tb["ktot"]), dtype=torch.float32, device=dz.device)
+        call("bts_conv_wgrad", C.byref(d), C.c_void_p(dz.data_ptr()), pix_stride(dz), C.c_void_p(dwp.data_ptr()), stream_ptr())
+        return self.unpack_wgrad(dwp, dtype)

@@ -1,0 +1,93 @@
+// Internal helpers shared by the gfx950 kernels of libbts_amd.so.
+// Nothing here is part of the C ABI (see include/bts_amd.h for that).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bts_amd.h"
+
+#define BTS_WAVE 64
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+}
+
+// Element traits: T = float or bf16 storage (uint16_t payload).
+struct F32 {
+    typedef float elem_t;
+    static constexpr int kBytes = 4;
+    static constexpr int kVec = 4;            // elements per 16-byte vector
+    static constexpr int kDtype = BTS_F32;
+    __device__ static __forceinline__ float ld(const void* p, size_t i) { return ((const float*)p)[i]; }
+    __device__ static __forceinline__ void st(void* p, size_t i, float v) { ((float*)p)[i] = v; }
+    // unpack a 16-byte vector into kVec floats / pack back
+    __device__ static __forceinline__ void unpack(const u32x4_t& v, float* f) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    __device__ static __forceinline__ u32x4_t pack(const float* f) {
+        u32x4_t v; v.x = __float_as_uint(f[0]); v.y = __float_as_uint(f[1]); v.z = __float_as_uint(f[2]); v.w = __float_as_uint(f[3]);
+        return v;
+    }
+};
+struct BF16 {
+    typedef uint16_t elem_t;
+    static constexpr int kBytes = 2;
+    static constexpr int kVec = 8;
+    static constexpr int kDtype = BTS_BF16;
+    __device__ static __forceinline__ float ld(const void* p, size_t i) { return bf16_bits_to_f32(((const uint16_t*)p)[i]); }
+    __device__ static __forceinline__ void st(void* p, size_t i, float v) { ((uint16_t*)p)[i] = (uint16_t)f32_to_bf16_bits(v); }
+    __device__ static __forceinline__ void unpack(const u32x4_t& v, float* f) {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+        f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+        f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    __device__ static __forceinline__ u32x4_t pack(const float* f) {
+        u32x4_t v; v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+        v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+        return v;
+    }
+};
+
+// ---- activations -----------------------------------------------------------
+__device__ __forceinline__ float act_elu(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ---- wave / block reductions -----------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+#define BTS_CHECK_ARG(cond)            \
+    do {                               \
+        if (!(cond)) return BTS_ERR_ARG; \
+    } while (0)
+
+#define BTS_LAUNCH_CHECK()                                       \
+    do {                                                         \
+        hipError_t e__ = hipGetLastError();                      \
+        if (e__ != hipSuccess) return BTS_ERR_LAUNCH;            \
+    } while (0)

@@ -1,0 +1,688 @@
+// Implicit-GEMM convolution for the BTS decoder on CDNA4 matrix cores (gfx950).
+//
+// One GEMM core (LDS tiles of [rows][128 B], XOR-swizzled, 32x32 MFMA tiles per wave)
+// with two staging front-ends:
+//   conv_igemm : D[co][pixel] = sum_{tap,k} W[co][tap][k] * X[pixel+tap][k]
+//                forward convs and data-gradients (same kernel, transformed weights);
+//                A = packed weights (K contiguous), B = NHWC pixels gathered per tap.
+//   conv_wgrad : dW[co][(tap,k)] = sum_pixel dZ[pixel][co] * X[pixel+tap][k]
+//                both operands are "K = pixel" so they are transposed in registers while
+//                being staged (8x8 bf16 / 4x4 f32 micro-tiles) into the same LDS image.
+// The wave computes C with lanes <-> B rows (pixels / weight columns) and accumulator
+// registers <-> A rows (output channels), so an NHWC pixel's channels come out as 4
+// consecutive registers -> 16-byte (f32) / 8-byte (bf16) stores.
+//
+// Replaces (as hand-written kernels) every Conv2d of pytorch/bts.py:51-80, 91-108, 153-194 and
+// torch.cat / F.interpolate(nearest) around them; see include/bts_amd.h for the descriptor.
+#include "common.h"
+
+namespace {
+
+struct FastDiv {
+    uint32_t m, s;
+};
+static FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    f.s = s;
+    f.m = (uint32_t)((((1ull << s) - d) << 32) / d + 1);
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return (__umulhi(n, f.m) + n) >> f.s; }
+
+struct ConvK {
+    const char* seg_ptr[BTS_MAX_SEG];
+    int seg_stride[BTS_MAX_SEG];
+    int seg_cum[BTS_MAX_SEG + 1];  // in 16-byte vectors
+    int nseg, KV;                  // KV = vectors per tap
+    int N, Hg, Wg, M;
+    FastDiv fd_w, fd_hw;
+    int Hx, Wx, isc;
+    int T, nphase, Ttot;
+    uint32_t taps[BTS_MAX_TAP];  // dy:8 | dx:8 | ioy:4 | iox:4
+    const char* w;
+    int Cout, Ktot;
+    char* y;
+    int y_stride, Hy, Wy, osc, y_f32, act, accumulate, vec_store;
+    float out_scale;
+    const float* out_scale_n;
+    int n_px_tiles, n_co_tiles;
+    // wgrad only
+    const char* dz;
+    int dz_stride;
+    float* dw;
+    int n_col_tiles, nchunks, chunks_per_split;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ int remap_xcd(int b, int nb) {
+    // blocks are dealt round-robin to the 8 XCDs; give each XCD a contiguous range of logical tiles
+    const int xcd = b & 7, q = nb >> 3, r = nb & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<BF16> {
+    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <>
+struct Mma<F32> {
+    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ void decode_tap(uint32_t tp, int& dy, int& dx, int& ioy, int& iox) {
+    dy = (int)(int8_t)(tp & 0xff);
+    dx = (int)(int8_t)((tp >> 8) & 0xff);
+    ioy = (tp >> 16) & 0xf;
+    iox = (tp >> 20) & 0xf;
+}
+
+// select the input segment that holds channel-vector cv
+__device__ __forceinline__ void pick_seg(const ConvK& a, int cv, const char*& sp, int& sst, int& coff) {
+    sp = a.seg_ptr[0];
+    sst = a.seg_stride[0];
+    coff = cv;
+#pragma unroll
+    for (int s = 1; s < BTS_MAX_SEG; ++s) {
+        if (s < a.nseg && cv >= a.seg_cum[s]) {
+            sp = a.seg_ptr[s];
+            sst = a.seg_stride[s];
+            coff = cv - a.seg_cum[s];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / data-gradient kernel
+// ------------------------------------------------------------------------------------------------
+template <typename T, int WR, int WC, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_igemm(const ConvK a) {
+    constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+    constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int VEC = T::kVec, ES = T::kBytes;
+    static_assert(WR * WC == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * 128 + BTS_MAX_TAP * 4];
+    char* sA = smem;
+    char* sB = smem + BM * 128;
+    uint32_t* sTap = (uint32_t*)(smem + (BM + BN) * 128);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int phase = blockIdx.y;
+    const int L = remap_xcd(blockIdx.x, a.n_px_tiles * a.n_co_tiles);
+    const int co_tile = L % a.n_co_tiles, px_tile = L / a.n_co_tiles;
+    if (tid < BTS_MAX_TAP) sTap[tid] = a.taps[tid];
+
+    const int vec = tid & 7, srow = tid >> 3;
+    // pixel rows staged by this thread (fixed for the whole K loop)
+    int py[RB], px[RB], pn[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int m = px_tile * BN + srow + 32 * i;
+        if (m < a.M) {
+            const uint32_t n = fdiv(m, a.fd_hw);
+            const uint32_t rem = m - n * (uint32_t)(a.Hg * a.Wg);
+            const uint32_t y = fdiv(rem, a.fd_w);
+            py[i] = (int)y;
+            px[i] = (int)(rem - y * a.Wg);
+            pn[i] = (int)n;
+        } else {
+            py[i] = px[i] = 0;
+            pn[i] = -1;
+        }
+    }
+    const int TKV = a.T * a.KV;
+    const int nchunks = (TKV + 7) >> 3;
+    const size_t w_phase_off = (size_t)phase * a.T * a.Ktot;
+    const size_t w_row = (size_t)a.Ttot * a.Ktot;
+
+    int tap = 0, cv = vec;
+    while (cv >= a.KV) { cv -= a.KV; ++tap; }
+
+    u32x4_t ra[RA], rb[RB];
+    __syncthreads();  // tap table visible
+
+    auto load_chunk = [&](int chunk) {
+        const int kv = chunk * 8 + vec;
+        const bool kok = kv < TKV;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int co = co_tile * BM + srow + 32 * i;
+            u32x4_t v = {0, 0, 0, 0};
+            if (kok && co < a.Cout) v = *(const u32x4_t*)(a.w + ((size_t)co * w_row + w_phase_off + (size_t)kv * VEC) * ES);
+            ra[i] = v;
+        }
+        int dy = 0, dx = 0, ioy = 0, iox = 0;
+        const char* sp; int sst, coff;
+        pick_seg(a, cv, sp, sst, coff);
+        if (kok) decode_tap(sTap[phase * a.T + tap], dy, dx, ioy, iox);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int yy = py[i] + dy, xx = px[i] + dx;
+            u32x4_t v = {0, 0, 0, 0};
+            if (kok && pn[i] >= 0 && (unsigned)yy < (unsigned)a.Hg && (unsigned)xx < (unsigned)a.Wg) {
+                const size_t pix = ((size_t)pn[i] * a.Hx + (yy * a.isc + ioy)) * a.Wx + (xx * a.isc + iox);
+                v = *(const u32x4_t*)(sp + (pix * sst + (size_t)coff * VEC) * ES);
+            }
+            rb[i] = v;
+        }
+        cv += 8;
+        while (cv >= a.KV) { cv -= a.KV; ++tap; }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *(u32x4_t*)(sA + lds_off(srow + 32 * i, vec)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *(u32x4_t*)(sB + lds_off(srow + 32 * i, vec)) = rb[i];
+    };
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wr = wave / WC, wc = wave % WC;
+    const int frow = lane & 31, fk = lane >> 5;
+
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        if (more) load_chunk(chunk + 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4_t fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4_t*)(sA + lds_off((wr * TM + i) * 32 + frow, 2 * s + fk));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *(const u32x4_t*)(sB + lds_off((wc * TN + j) * 32 + frow, 2 * s + fk));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lanes <-> pixels, registers <-> channels -------------------------------
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int m = px_tile * BN + (wc * TN + j) * 32 + frow;
+        if (m >= a.M) continue;
+        const uint32_t n = fdiv(m, a.fd_hw);
+        const uint32_t rem = m - n * (uint32_t)(a.Hg * a.Wg);
+        const uint32_t y = fdiv(rem, a.fd_w);
+        const uint32_t x = rem - y * a.Wg;
+        const size_t opix = ((size_t)n * a.Hy + (y * a.osc + (phase >> 1))) * a.Wy + (x * a.osc + (phase & 1));
+        float sc = a.out_scale;
+        if (a.out_scale_n) sc *= a.out_scale_n[n];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = co_tile * BM + (wr * TM + i) * 32 + 8 * q + 4 * fk;
+                if (co >= a.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[i][j][4 * q + e];
+                    if (a.act == BTS_ACT_ELU) t = act_elu(t);
+                    else if (a.act == BTS_ACT_SIGMOID) t = act_sigmoid(t);
+                    else if (a.act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
+                    v[e] = t * sc;
+                }
+                const size_t o = opix * a.y_stride + co;
+                if (a.vec_store) {
+                    if (a.y_f32) {
+                        float* p = (float*)a.y + o;
+                        f32x4_t t = {v[0], v[1], v[2], v[3]};
+                        if (a.accumulate) { f32x4_t old = *(f32x4_t*)p; t += old; }
+                        *(f32x4_t*)p = t;
+                    } else {
+                        uint16_t* p = (uint16_t*)a.y + o;
+                        if (a.accumulate) {
+                            u32x2_t old = *(u32x2_t*)p;
+                            v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                            v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+                        }
+                        u32x2_t t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *(u32x2_t*)p = t;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e >= a.Cout) break;
+                        if (a.y_f32) {
+                            float* p = (float*)a.y + o + e;
+                            *p = a.accumulate ? *p + v[e] : v[e];
+                        } else {
+                            uint16_t* p = (uint16_t*)a.y + o + e;
+                            const float t = a.accumulate ? bf16_bits_to_f32(*p) + v[e] : v[e];
+                            *p = (uint16_t)f32_to_bf16_bits(t);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight-gradient kernel
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct Transpose;
+template <>
+struct Transpose<BF16> {  // in[p] = 8 channels of pixel p  ->  out[c] = 8 pixels of channel c
+    __device__ static __forceinline__ void run(const u32x4_t (&in)[8], u32x4_t (&out)[8]) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            uint32_t o[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t lo = in[2 * d][c >> 1], hi = in[2 * d + 1][c >> 1];
+                o[d] = (c & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+            }
+            out[c] = u32x4_t{o[0], o[1], o[2], o[3]};
+        }
+    }
+};
+template <>
+struct Transpose<F32> {
+    __device__ static __forceinline__ void run(const u32x4_t (&in)[4], u32x4_t (&out)[4]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[c] = u32x4_t{in[0][c], in[1][c], in[2][c], in[3][c]};
+    }
+};
+
+template <typename T, int WR, int WC, int WK, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_wgrad(const ConvK a) {
+    constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+    constexpr int VEC = T::kVec, ES = T::kBytes;
+    constexpr int PK = 8 * VEC;                       // pixels per K chunk (128 B of LDS row)
+    constexpr int NMT_A = BM / VEC * 8, NMT_B = BN / VEC * 8;  // micro-tiles (VEC ch x VEC px)
+    constexpr int NIT = (NMT_A + NMT_B + 255) / 256;
+    static_assert(WR * WC * WK == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * 128 + BTS_MAX_TAP * 4];
+    char* sA = smem;
+    char* sB = smem + BM * 128;
+    uint32_t* sTap = (uint32_t*)(smem + (BM + BN) * 128);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int phase = blockIdx.z, split = blockIdx.y;
+    const int L = blockIdx.x;
+    const int co_tile = L % a.n_co_tiles, col_tile = L / a.n_co_tiles;
+    if (tid < BTS_MAX_TAP) sTap[tid] = a.taps[tid];
+    __syncthreads();
+
+    const int TKV = a.T * a.KV;
+    // per-thread micro-tile descriptors (fixed over the K loop)
+    bool isA[NIT], live[NIT];
+    int rg[NIT], cc[NIT];                 // row group (VEC rows) and 16-byte chunk column (VEC pixels)
+    const char* bptr[NIT]; int bstride[NIT];  // A: dz base (+channel offset) ; B: segment base (+channel offset)
+    int bdy[NIT], bdx[NIT], bioy[NIT], biox[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int mt = tid + it * 256;
+        isA[it] = mt < NMT_A;
+        const int mtl = isA[it] ? mt : mt - NMT_A;
+        cc[it] = mtl & 7;
+        rg[it] = mtl >> 3;
+        live[it] = mt < NMT_A + NMT_B;
+        bdy[it] = bdx[it] = bioy[it] = biox[it] = 0;
+        bptr[it] = nullptr; bstride[it] = 0;
+        if (!live[it]) continue;
+        if (isA[it]) {
+            const int co0 = co_tile * BM + rg[it] * VEC;
+            live[it] = co0 < a.Cout;           // dz is readable (zero padded) up to a multiple of VEC
+            bptr[it] = a.dz + (size_t)co0 * ES;
+            bstride[it] = a.dz_stride;
+        } else {
+            const int colv = col_tile * (BN / VEC) + rg[it];
+            live[it] = colv < TKV;
+            if (live[it]) {
+                const int t = colv / a.KV, cv = colv - t * a.KV;
+                const char* sp; int sst, coff;
+                pick_seg(a, cv, sp, sst, coff);
+                bptr[it] = sp + (size_t)coff * VEC * ES;
+                bstride[it] = sst;
+                decode_tap(sTap[phase * a.T + t], bdy[it], bdx[it], bioy[it], biox[it]);
+            }
+        }
+    }
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wk = wave % WK, wrc = wave / WK;
+    const int wr = wrc / WC, wc = wrc % WC;
+    const int frow = lane & 31, fk = lane >> 5;
+    const int pa = phase >> 1, pb = phase & 1;
+
+    const int c_begin = split * a.chunks_per_split;
+    const int c_end = min(a.nchunks, c_begin + a.chunks_per_split);
+
+    u32x4_t stage[NIT][VEC];
+    auto load_chunk = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int m0 = chunk * PK + cc[it] * VEC;
+            uint32_t n = 0, y = 0, x = 0;
+            if (live[it] && m0 < a.M) {
+                n = fdiv(m0, a.fd_hw);
+                const uint32_t rem = m0 - n * (uint32_t)(a.Hg * a.Wg);
+                y = fdiv(rem, a.fd_w);
+                x = rem - y * a.Wg;
+            }
+#pragma unroll
+            for (int p = 0; p < VEC; ++p) {
+                u32x4_t v = {0, 0, 0, 0};
+                if (live[it] && m0 + p < a.M) {
+                    if (isA[it]) {
+                        const size_t pix = ((size_t)n * a.Hy + (y * a.osc + pa)) * a.Wy + (x * a.osc + pb);
+                        v = *(const u32x4_t*)(bptr[it] + pix * bstride[it] * ES);
+                    } else {
+                        const int yy = (int)y + bdy[it], xx = (int)x + bdx[it];
+                        if ((unsigned)yy < (unsigned)a.Hg && (unsigned)xx < (unsigned)a.Wg) {
+                            const size_t pix = ((size_t)n * a.Hx + (yy * a.isc + bioy[it])) * a.Wx + (xx * a.isc + biox[it]);
+                            v = *(const u32x4_t*)(bptr[it] + pix * bstride[it] * ES);
+                        }
+                    }
+                }
+                stage[it][p] = v;
+                if (++x == (uint32_t)a.Wg) { x = 0; if (++y == (uint32_t)a.Hg) { y = 0; ++n; } }
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (tid + it * 256 >= NMT_A + NMT_B) continue;
+            u32x4_t tr[VEC];
+            Transpose<T>::run(stage[it], tr);
+            char* base = isA[it] ? sA : sB;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) *(u32x4_t*)(base + lds_off(rg[it] * VEC + c, cc[it])) = tr[c];
+        }
+    };
+
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk();
+        __syncthreads();
+        for (int chunk = c_begin; chunk < c_end; ++chunk) {
+            const bool more = chunk + 1 < c_end;
+            if (more) load_chunk(chunk + 1);
+#pragma unroll
+            for (int s = wk; s < 4; s += WK) {
+                u32x4_t fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4_t*)(sA + lds_off((wr * TM + i) * 32 + frow, 2 * s + fk));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = *(const u32x4_t*)(sB + lds_off((wc * TN + j) * 32 + frow, 2 * s + fk));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+            }
+            __syncthreads();
+            if (more) {
+                store_chunk();
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: f32 atomics into dw[co][phase*T*Ktot + col] ------------------------------
+    const size_t row_len = (size_t)a.Ttot * a.Ktot;
+    const int TK = a.T * a.Ktot;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col_tile * BN + (wc * TN + j) * 32 + frow;
+        if (col >= TK) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_tile * BM + (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (co < a.Cout) atomicAdd(a.dw + (size_t)co * row_len + (size_t)phase * TK + col, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing / gradient unpacking
+// ------------------------------------------------------------------------------------------------
+struct PackK {
+    const float* w;
+    int Cout, Cin, KK, mode;
+    const int32_t* cmap;
+    int R, K, T;
+    uint16_t tapmask[BTS_MAX_TAP];
+    void* out;
+    const float* dwp;
+    const int32_t* kinv;
+    float* gw;
+    int accumulate;
+};
+
+template <typename T>
+__global__ void pack_weight_kernel(const PackK a) {
+    const long total = (long)a.R * a.T * a.K;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % a.K);
+        const int t = (int)((idx / a.K) % a.T);
+        const int r = (int)(idx / ((long)a.K * a.T));
+        float v = 0.f;
+        int co, ci;
+        if (a.mode == 0) { co = r; ci = a.cmap[k]; }
+        else { co = k; ci = a.cmap[r]; }
+        if (ci >= 0 && co < a.Cout) {
+            const float* p = a.w + ((size_t)co * a.Cin + ci) * a.KK;
+            const uint32_t mask = a.tapmask[t];
+            for (int s = 0; s < a.KK; ++s) if (mask & (1u << s)) v += p[s];
+        }
+        T::st(a.out, idx, v);
+    }
+}
+
+__global__ void unpack_wgrad_kernel(const PackK a) {
+    const long total = (long)a.Cout * a.Cin * a.KK;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(idx % a.KK);
+        const int ci = (int)((idx / a.KK) % a.Cin);
+        const int co = (int)(idx / ((long)a.KK * a.Cin));
+        const int k = a.kinv[ci];
+        float v = 0.f;
+        for (int t = 0; t < a.T; ++t)
+            if (a.tapmask[t] & (1u << s)) v += a.dwp[((size_t)co * a.T + t) * a.K + k];
+        a.gw[idx] = a.accumulate ? a.gw[idx] + v : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int fill_common(const bts_conv_desc_t* d, ConvK& k) {
+    BTS_CHECK_ARG(d != nullptr);
+    BTS_CHECK_ARG(d->dtype == BTS_F32 || d->dtype == BTS_BF16);
+    const int VEC = d->dtype == BTS_F32 ? 4 : 8;
+    BTS_CHECK_ARG(d->N > 0 && d->Hg > 0 && d->Wg > 0 && d->Hx > 0 && d->Wx > 0);
+    BTS_CHECK_ARG(d->nseg >= 1 && d->nseg <= BTS_MAX_SEG);
+    BTS_CHECK_ARG(d->nphase == 1 || d->nphase == 4);
+    BTS_CHECK_ARG(d->T >= 1 && d->nphase * d->T <= BTS_MAX_TAP);
+    BTS_CHECK_ARG(d->isc >= 1 && d->isc <= 2 && d->osc >= 1 && d->osc <= 2);
+    BTS_CHECK_ARG(d->Cout >= 1);
+    BTS_CHECK_ARG((long)d->N * d->Hg * d->Wg < (1l << 31));
+    int cum = 0;
+    for (int s = 0; s < BTS_MAX_SEG; ++s) {
+        k.seg_cum[s] = cum;
+        if (s < d->nseg) {
+            BTS_CHECK_ARG(d->seg[s].ptr != nullptr && d->seg[s].C > 0 && d->seg[s].C % VEC == 0);
+            BTS_CHECK_ARG(d->seg[s].stride >= d->seg[s].C && d->seg[s].stride % VEC == 0);
+            BTS_CHECK_ARG(((uintptr_t)d->seg[s].ptr & 15) == 0);
+            k.seg_ptr[s] = (const char*)d->seg[s].ptr;
+            k.seg_stride[s] = d->seg[s].stride;
+            cum += d->seg[s].C / VEC;
+        } else {
+            k.seg_ptr[s] = nullptr;
+            k.seg_stride[s] = 0;
+        }
+    }
+    k.seg_cum[BTS_MAX_SEG] = cum;
+    k.nseg = d->nseg;
+    k.KV = cum;
+    k.Ktot = cum * VEC;
+    k.N = d->N; k.Hg = d->Hg; k.Wg = d->Wg; k.M = d->N * d->Hg * d->Wg;
+    k.fd_w = make_fastdiv(d->Wg);
+    k.fd_hw = make_fastdiv(d->Hg * d->Wg);
+    k.Hx = d->Hx; k.Wx = d->Wx; k.isc = d->isc;
+    k.T = d->T; k.nphase = d->nphase; k.Ttot = d->nphase * d->T;
+    for (int t = 0; t < BTS_MAX_TAP; ++t) {
+        uint32_t v = 0;
+        if (t < k.Ttot) {
+            BTS_CHECK_ARG(d->dy[t] >= -127 && d->dy[t] <= 127 && d->dx[t] >= -127 && d->dx[t] <= 127);
+            BTS_CHECK_ARG(d->ioy[t] >= 0 && d->ioy[t] < 16 && d->iox[t] >= 0 && d->iox[t] < 16);
+            v = (uint32_t)(uint8_t)(int8_t)d->dy[t] | ((uint32_t)(uint8_t)(int8_t)d->dx[t] << 8) |
+                ((uint32_t)d->ioy[t] << 16) | ((uint32_t)d->iox[t] << 20);
+        }
+        k.taps[t] = v;
+    }
+    k.Cout = d->Cout;
+    k.Hy = d->Hy; k.Wy = d->Wy; k.osc = d->osc;
+    return BTS_OK;
+}
+
+template <typename T>
+static int launch_fwd(const ConvK& k0, hipStream_t st) {
+    ConvK k = k0;
+    auto go = [&](auto kern, int BM, int BN) {
+        k.n_co_tiles = ceil_div(k.Cout, BM);
+        k.n_px_tiles = ceil_div(k.M, BN);
+        dim3 grid(k.n_co_tiles * k.n_px_tiles, k.nphase);
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, k);
+    };
+    if (k.Cout > 64) go(conv_igemm<T, 2, 2, 2, 2>, 128, 128);
+    else if (k.Cout > 32) go(conv_igemm<T, 1, 4, 2, 2>, 64, 256);
+    else go(conv_igemm<T, 1, 4, 1, 2>, 32, 256);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+template <typename T>
+static int launch_wgrad(const ConvK& k0, hipStream_t st) {
+    ConvK k = k0;
+    constexpr int PK = 8 * T::kVec;
+    auto go = [&](auto kern, int BM) {
+        k.n_co_tiles = ceil_div(k.Cout, BM);
+        k.n_col_tiles = ceil_div((long)k.T * k.Ktot, 128);
+        k.nchunks = ceil_div(k.M, PK);
+        const int tiles = k.n_co_tiles * k.n_col_tiles * k.nphase;
+        int splits = ceil_div(1536, tiles);
+        if (splits > k.nchunks) splits = k.nchunks;
+        if (splits < 1) splits = 1;
+        k.chunks_per_split = ceil_div(k.nchunks, splits);
+        splits = ceil_div(k.nchunks, k.chunks_per_split);
+        dim3 grid(k.n_co_tiles * k.n_col_tiles, splits, k.nphase);
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, k);
+    };
+    if (k.Cout > 64) go(conv_wgrad<T, 2, 2, 1, 2, 2>, 128);
+    else if (k.Cout > 32) go(conv_wgrad<T, 1, 2, 2, 2, 2>, 64);
+    else go(conv_wgrad<T, 1, 1, 4, 1, 4>, 32);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+}  // namespace
+
+extern "C" int bts_conv_fwd(const bts_conv_desc_t* d, bts_stream_t stream) {
+    ConvK k{};
+    int rc = fill_common(d, k);
+    if (rc != BTS_OK) return rc;
+    BTS_CHECK_ARG(d->w != nullptr && d->y != nullptr && ((uintptr_t)d->w & 15) == 0);
+    BTS_CHECK_ARG(d->y_dtype == BTS_F32 || d->y_dtype == BTS_BF16);
+    BTS_CHECK_ARG(d->y_stride >= 1 && d->Hy >= d->Hg * d->osc && d->Wy >= d->Wg * d->osc);
+    BTS_CHECK_ARG(d->act >= BTS_ACT_NONE && d->act <= BTS_ACT_RELU);
+    BTS_CHECK_ARG(!(d->accumulate && d->act != BTS_ACT_NONE));
+    BTS_CHECK_ARG(d->nphase == 1 || d->osc == 2);
+    k.w = (const char*)d->w;
+    k.y = (char*)d->y;
+    k.y_stride = d->y_stride;
+    k.y_f32 = d->y_dtype == BTS_F32;
+    k.act = d->act;
+    k.accumulate = d->accumulate;
+    k.out_scale = d->out_scale;
+    k.out_scale_n = d->out_scale_n;
+    const int ob = k.y_f32 ? 16 : 8;
+    k.vec_store = (d->Cout % 4 == 0) && (d->y_stride % 4 == 0) && (((uintptr_t)d->y & (ob - 1)) == 0);
+    return d->dtype == BTS_F32 ? launch_fwd<F32>(k, (hipStream_t)stream) : launch_fwd<BF16>(k, (hipStream_t)stream);
+}
+
+extern "C" int bts_conv_wgrad(const bts_conv_desc_t* d, const void* dz, int dz_stride, float* dw, bts_stream_t stream) {
+    ConvK k{};
+    int rc = fill_common(d, k);
+    if (rc != BTS_OK) return rc;
+    const int VEC = d->dtype == BTS_F32 ? 4 : 8;
+    BTS_CHECK_ARG(dz != nullptr && dw != nullptr && ((uintptr_t)dz & 15) == 0);
+    BTS_CHECK_ARG(dz_stride % VEC == 0 && dz_stride >= (d->Cout + VEC - 1) / VEC * VEC);
+    BTS_CHECK_ARG(d->Hy >= d->Hg * d->osc && d->Wy >= d->Wg * d->osc);
+    k.dz = (const char*)dz;
+    k.dz_stride = dz_stride;
+    k.dw = dw;
+    return d->dtype == BTS_F32 ? launch_wgrad<F32>(k, (hipStream_t)stream) : launch_wgrad<BF16>(k, (hipStream_t)stream);
+}
+
+extern "C" int bts_pack_weight(const float* w, int Cout, int Cin, int KK, int mode, const int32_t* cmap, int R, int K,
+                               int T, const uint16_t* tapmask, int dtype, void* out, bts_stream_t stream) {
+    BTS_CHECK_ARG(w && cmap && tapmask && out);
+    BTS_CHECK_ARG(Cout > 0 && Cin > 0 && (KK == 1 || KK == 9) && (mode == 0 || mode == 1));
+    BTS_CHECK_ARG(R > 0 && K > 0 && T >= 1 && T <= BTS_MAX_TAP);
+    BTS_CHECK_ARG(dtype == BTS_F32 || dtype == BTS_BF16);
+    PackK a{};
+    a.w = w; a.Cout = Cout; a.Cin = Cin; a.KK = KK; a.mode = mode; a.cmap = cmap; a.R = R; a.K = K; a.T = T; a.out = out;
+    for (int t = 0; t < T; ++t) a.tapmask[t] = tapmask[t];
+    const long total = (long)R * T * K;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (dtype == BTS_F32) hipLaunchKernelGGL(pack_weight_kernel<F32>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(pack_weight_kernel<BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_unpack_wgrad(const float* dwp, int Cout, int Cin, int KK, const int32_t* kinv, int K, int T,
+                                const uint16_t* tapmask, float* gw, int accumulate, bts_stream_t stream) {
+    BTS_CHECK_ARG(dwp && kinv && tapmask && gw);
+    BTS_CHECK_ARG(Cout > 0 && Cin > 0 && (KK == 1 || KK == 9) && K > 0 && T >= 1 && T <= BTS_MAX_TAP);
+    PackK a{};
+    a.dwp = dwp; a.Cout = Cout; a.Cin = Cin; a.KK = KK; a.kinv = kinv; a.K = K; a.T = T; a.gw = gw; a.accumulate = accumulate;
+    for (int t = 0; t < T; ++t) a.tapmask[t] = tapmask[t];
+    const long total = (long)Cout * Cin * KK;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}

@@ -1,0 +1,559 @@
+// HBM-bound elementwise / normalisation kernels of the BTS decoder for gfx950.
+//
+// Everything here streams NHWC tensors ([M pixels][C channels], pixel stride given) with
+// 16-byte vector accesses: a thread owns one 16-byte channel vector (4 f32 / 8 bf16) and walks
+// pixels, so per-channel parameters (BN scale/shift, mean, ...) are loaded once into registers.
+// Block = (BX channel-vector lanes) x (256/BX pixel lanes); BX is the smallest power of two
+// >= min(C/VEC, 32) so narrow tensors (C = 32..64) still fill their wavefronts.
+//
+// Replaces nn.BatchNorm2d (train + eval), nn.ReLU, the ELU/sigmoid backward passes and the
+// NCHW<->NHWC boundary conversions around pytorch/bts.py:196-266.
+#include "common.h"
+
+namespace {
+
+struct Shape2 {
+    long M;
+    int CV;  // channel vectors
+};
+
+__device__ __forceinline__ void thread_coords(int bx_log2, int& cv, long& p0, long& pstep, const Shape2& s) {
+    const int bx = 1 << bx_log2;
+    const int tx = threadIdx.x & (bx - 1), ty = threadIdx.x >> bx_log2;
+    cv = blockIdx.y * bx + tx;
+    const int by = 256 >> bx_log2;
+    p0 = (long)blockIdx.x * by + ty;
+    pstep = (long)gridDim.x * by;
+}
+
+static void pick_grid(long M, int CV, int& bx_log2, dim3& grid, int max_blocks = 4096) {
+    bx_log2 = 0;
+    while ((1 << bx_log2) < CV && bx_log2 < 5) ++bx_log2;
+    const int bx = 1 << bx_log2, by = 256 >> bx_log2;
+    const int gy = (CV + bx - 1) / bx;
+    long gx = (M + by - 1) / by;
+    const long cap = max_blocks / gy > 0 ? max_blocks / gy : 1;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    grid = dim3((unsigned)gx, (unsigned)gy);
+}
+
+template <typename T>
+__device__ __forceinline__ void ldv(const void* base, size_t elem_off, float* f) {
+    T::unpack(*(const u32x4_t*)((const char*)base + elem_off * T::kBytes), f);
+}
+template <typename T>
+__device__ __forceinline__ void stv(void* base, size_t elem_off, const float* f) {
+    *(u32x4_t*)((char*)base + elem_off * T::kBytes) = T::pack(f);
+}
+
+// ---- y = act(x*scale + shift) ------------------------------------------------------------------
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void affine_act_kernel(const void* __restrict__ x, int xs, void* __restrict__ y, int ys,
+                                                         Shape2 s, int bxl, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int act) {
+    static_assert(TX::kVec == TY::kVec, "same vector width");
+    constexpr int V = TX::kVec;
+    int cv; long p, ps;
+    thread_coords(bxl, cv, p, ps, s);
+    if (cv >= s.CV) return;
+    float sc[V], sh[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { sc[e] = scale ? scale[cv * V + e] : 1.f; sh[e] = shift ? shift[cv * V + e] : 0.f; }
+    for (; p < s.M; p += ps) {
+        float f[V];
+        ldv<TX>(x, (size_t)p * xs + cv * V, f);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float t = f[e] * sc[e] + sh[e];
+            if (act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
+            f[e] = t;
+        }
+        stv<TY>(y, (size_t)p * ys + cv * V, f);
+    }
+}
+
+// ---- batch statistics --------------------------------------------------------------------------
+// pass 1: per-block partial sums  ws[block][2][Cpad]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const void* __restrict__ x, int xs, Shape2 s, int bxl,
+                                                               float* __restrict__ ws, int Cpad) {
+    constexpr int V = T::kVec;
+    int cv; long p, ps;
+    thread_coords(bxl, cv, p, ps, s);
+    float a[V], b[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] = b[e] = 0.f;
+    if (cv < s.CV) {
+        for (; p < s.M; p += ps) {
+            float f[V];
+            ldv<T>(x, (size_t)p * xs + cv * V, f);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { a[e] += f[e]; b[e] += f[e] * f[e]; }
+        }
+    }
+    // reduce over the pixel lanes (ty) of the block through LDS
+    __shared__ float red[256][2 * 8 + 1];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { red[threadIdx.x][e] = a[e]; red[threadIdx.x][8 + e] = b[e]; }
+    __syncthreads();
+    const int bx = 1 << bxl, by = 256 >> bxl;
+    if (threadIdx.x < bx && cv < s.CV) {   // ty == 0 lanes
+        for (int e = 0; e < V; ++e) {
+            float sa = 0.f, sb = 0.f;
+            for (int t = 0; t < by; ++t) { sa += red[t * bx + threadIdx.x][e]; sb += red[t * bx + threadIdx.x][8 + e]; }
+            ws[((size_t)blockIdx.x * 2 + 0) * Cpad + cv * V + e] = sa;
+            ws[((size_t)blockIdx.x * 2 + 1) * Cpad + cv * V + e] = sb;
+        }
+    }
+}
+
+// pass 2: combine partials in double. mode 0: out0 = mean, out1 = biased var ; mode 1: out0 = sum0, out1 = sum1
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ ws, int nparts, int C, int Cpad,
+                                                             double M, int mode, float* __restrict__ out0,
+                                                             float* __restrict__ out1) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double a = 0, b = 0;
+    for (int k = 0; k < nparts; ++k) { a += ws[((size_t)k * 2 + 0) * Cpad + c]; b += ws[((size_t)k * 2 + 1) * Cpad + c]; }
+    if (mode == 0) {
+        const double mean = a / M;
+        double var = b / M - mean * mean;
+        if (var < 0) var = 0;
+        out0[c] = (float)mean; out1[c] = (float)var;
+    } else {
+        out0[c] = (float)a; out1[c] = (float)b;
+    }
+}
+
+// scale/shift/invstd from statistics + running-stat update (nn.BatchNorm2d train semantics: momentum,
+// unbiased variance for the running estimate)
+__global__ __launch_bounds__(256) void bn_prepare_kernel(const float* __restrict__ mean, const float* __restrict__ var, int C,
+                                                         double M, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, float momentum,
+                                                         float* __restrict__ rmean, float* __restrict__ rvar,
+                                                         float* __restrict__ invstd, float* __restrict__ scale,
+                                                         float* __restrict__ shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float m = mean[c], v = var[c];
+    const float is = 1.f / sqrtf(v + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    if (invstd) invstd[c] = is;
+    scale[c] = g * is;
+    shift[c] = b - m * g * is;
+    if (rmean) {
+        const float unb = M > 1.0 ? (float)((double)v * (M / (M - 1.0))) : v;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    }
+}
+
+// ---- BatchNorm(+ReLU) backward -------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const void* __restrict__ dy, int dys, const void* __restrict__ x,
+                                                             int xs, Shape2 s, int bxl, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int relu,
+                                                             float* __restrict__ ws, int Cpad) {
+    constexpr int V = T::kVec;
+    int cv; long p, ps;
+    thread_coords(bxl, cv, p, ps, s);
+    float a[V], b[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] = b[e] = 0.f;
+    if (cv < s.CV) {
+        float mu[V], is[V], g[V], be[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            mu[e] = mean[cv * V + e]; is[e] = invstd[cv * V + e];
+            g[e] = gamma ? gamma[cv * V + e] : 1.f; be[e] = beta ? beta[cv * V + e] : 0.f;
+        }
+        for (; p < s.M; p += ps) {
+            float fx[V], fd[V];
+            ldv<T>(x, (size_t)p * xs + cv * V, fx);
+            ldv<T>(dy, (size_t)p * dys + cv * V, fd);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float xh = (fx[e] - mu[e]) * is[e];
+                float d = fd[e];
+                if (relu && !(xh * g[e] + be[e] > 0.f)) d = 0.f;
+                a[e] += d; b[e] += d * xh;
+            }
+        }
+    }
+    __shared__ float red[256][2 * 8 + 1];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { red[threadIdx.x][e] = a[e]; red[threadIdx.x][8 + e] = b[e]; }
+    __syncthreads();
+    const int bx = 1 << bxl, by = 256 >> bxl;
+    if (threadIdx.x < bx && cv < s.CV) {
+        for (int e = 0; e < V; ++e) {
+            float sa = 0.f, sb = 0.f;
+            for (int t = 0; t < by; ++t) { sa += red[t * bx + threadIdx.x][e]; sb += red[t * bx + threadIdx.x][8 + e]; }
+            ws[((size_t)blockIdx.x * 2 + 0) * Cpad + cv * V + e] = sa;
+            ws[((size_t)blockIdx.x * 2 + 1) * Cpad + cv * V + e] = sb;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ dy, int dys, const void* __restrict__ x,
+                                                           int xs, void* __restrict__ dx, int dxs, Shape2 s, int bxl,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           int relu, const float* __restrict__ sums, int C, int use_batch,
+                                                           int accumulate) {
+    constexpr int V = T::kVec;
+    int cv; long p, ps;
+    thread_coords(bxl, cv, p, ps, s);
+    if (cv >= s.CV) return;
+    float mu[V], is[V], g[V], be[V], k0[V], k1[V];
+    const float invM = 1.f / (float)s.M;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const int c = cv * V + e;
+        mu[e] = mean[c]; is[e] = invstd[c];
+        g[e] = gamma ? gamma[c] : 1.f; be[e] = beta ? beta[c] : 0.f;
+        k0[e] = use_batch ? sums[c] * invM : 0.f;
+        k1[e] = use_batch ? sums[C + c] * invM : 0.f;
+    }
+    for (; p < s.M; p += ps) {
+        float fx[V], fd[V], o[V];
+        ldv<T>(x, (size_t)p * xs + cv * V, fx);
+        ldv<T>(dy, (size_t)p * dys + cv * V, fd);
+        if (accumulate) ldv<T>(dx, (size_t)p * dxs + cv * V, o);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float xh = (fx[e] - mu[e]) * is[e];
+            float d = fd[e];
+            if (relu && !(xh * g[e] + be[e] > 0.f)) d = 0.f;
+            const float r = g[e] * is[e] * (d - k0[e] - xh * k1[e]);
+            o[e] = accumulate ? o[e] + r : r;
+        }
+        stv<T>(dx, (size_t)p * dxs + cv * V, o);
+    }
+}
+
+// ---- activation backward (generic scalar indexing: also used for the 1-channel f32 maps) ---------
+template <typename TD, typename TY, typename TZ>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const void* __restrict__ dy, int dys, const void* __restrict__ y, int ys,
+                                                      void* __restrict__ dz, int dzs, long M, int C, int act, float y_scale,
+                                                      const float* __restrict__ y_scale_n, long ppi) {
+    const long total = M * C;
+    for (long i = blockIdx.x * 256l + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / C;
+        const int c = (int)(i - p * C);
+        const float g = TD::ld(dy, (size_t)p * dys + c);
+        float v = TY::ld(y, (size_t)p * ys + c);
+        float sc = y_scale;
+        if (y_scale_n) sc *= y_scale_n[p / ppi];
+        float r;
+        if (act == BTS_ACT_ELU) r = g * (v > 0.f ? 1.f : v + 1.f);
+        else if (act == BTS_ACT_RELU) r = v > 0.f ? g : 0.f;
+        else if (act == BTS_ACT_SIGMOID) { const float sg = v / sc; r = g * sc * sg * (1.f - sg); }
+        else r = g * sc;
+        TZ::st(dz, (size_t)p * dzs + c, r);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_vec_kernel(const void* __restrict__ dy, int dys, const void* __restrict__ y, int ys,
+                                                          void* __restrict__ dz, int dzs, Shape2 s, int bxl, int act) {
+    constexpr int V = T::kVec;
+    int cv; long p, ps;
+    thread_coords(bxl, cv, p, ps, s);
+    if (cv >= s.CV) return;
+    for (; p < s.M; p += ps) {
+        float g[V], v[V];
+        ldv<T>(dy, (size_t)p * dys + cv * V, g);
+        ldv<T>(y, (size_t)p * ys + cv * V, v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            if (act == BTS_ACT_ELU) g[e] = g[e] * (v[e] > 0.f ? 1.f : v[e] + 1.f);
+            else if (act == BTS_ACT_RELU) g[e] = v[e] > 0.f ? g[e] : 0.f;
+        }
+        stv<T>(dz, (size_t)p * dzs + cv * V, g);
+    }
+}
+
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void add_to_kernel(const void* __restrict__ x, int xs, void* __restrict__ y, int ys, long M,
+                                                     int C, int accumulate) {
+    const long total = M * C;
+    for (long i = blockIdx.x * 256l + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / C;
+        const int c = (int)(i - p * C);
+        float v = TX::ld(x, (size_t)p * xs + c);
+        if (accumulate) v += TY::ld(y, (size_t)p * ys + c);
+        TY::st(y, (size_t)p * ys + c, v);
+    }
+}
+
+// ---- NCHW f32 <-> NHWC -------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restrict__ dst, int ds,
+                                                           int C, int HW, int relu) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, p = p0 + tx;
+        float v = 0.f;
+        if (c < C && p < HW) v = src[((size_t)n * C + c) * HW + p];
+        if (relu) v = fmaxf(v, 0.f);
+        tile[k][tx] = v;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int p = p0 + k, c = c0 + tx;
+        if (c < C && p < HW) T::st(dst, ((size_t)n * HW + p) * ds + c, tile[tx][k]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restrict__ src, int ss, float* __restrict__ dst,
+                                                           const float* __restrict__ relu_src, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int p = p0 + k, c = c0 + tx;
+        float v = 0.f;
+        if (c < C && p < HW) v = T::ld(src, ((size_t)n * HW + p) * ss + c);
+        tile[k][tx] = v;   // [pixel][channel]
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, p = p0 + tx;
+        if (c < C && p < HW) {
+            const size_t o = ((size_t)n * C + c) * HW + p;
+            float v = tile[tx][k];
+            if (relu_src && !(relu_src[o] > 0.f)) v = 0.f;
+            dst[o] = v;
+        }
+    }
+}
+
+// ---- fused multi-tensor AdamW --------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ params, float* const* __restrict__ grads,
+                                                    float* const* __restrict__ m1, float* const* __restrict__ m2,
+                                                    const long* __restrict__ sizes, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2) {
+    const int t = blockIdx.y;
+    const long n = sizes[t];
+    float* p = params[t]; const float* g = grads[t]; float* a = m1[t]; float* b = m2[t];
+    const float step = lr / bc1, rs = rsqrtf(bc2);
+    for (long i = blockIdx.x * 256l + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i];
+        float pi = p[i] * (1.f - lr * wd);                 // decoupled weight decay (torch.optim.AdamW)
+        const float ai = b1 * a[i] + (1.f - b1) * gi;
+        const float bi = b2 * b[i] + (1.f - b2) * gi * gi;
+        a[i] = ai; b[i] = bi;
+        pi -= step * ai / (sqrtf(bi) * rs + eps);
+        p[i] = pi;
+    }
+}
+
+#define DISPATCH_T(dt, FN, ...)                       \
+    do {                                              \
+        if ((dt) == BTS_F32) { FN(F32, __VA_ARGS__); } \
+        else { FN(BF16, __VA_ARGS__); }               \
+    } while (0)
+
+static bool vec_ok(int dtype, int C, int stride, const void* p) {
+    const int V = dtype == BTS_F32 ? 4 : 8;
+    return C % V == 0 && stride % V == 0 && ((uintptr_t)p & 15) == 0;
+}
+static int flat_blocks(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+static int bn_parts(long M, int CV) {
+    int bxl; dim3 g;
+    pick_grid(M, CV, bxl, g, 2048);
+    return (int)g.x;
+}
+extern "C" long bts_bn_stats_workspace_bytes(long M, int C) {
+    const int Cpad = (C + 7) / 8 * 8;
+    const int p4 = bn_parts(M, (C + 3) / 4), p8 = bn_parts(M, (C + 7) / 8);
+    return (long)(p4 > p8 ? p4 : p8) * 2 * Cpad * sizeof(float) + 64;
+}
+
+extern "C" int bts_bn_stats(const void* x, int dtype, int stride, long M, int C, void* workspace, float* mean, float* var,
+                            bts_stream_t stream) {
+    BTS_CHECK_ARG(x && workspace && mean && var && M > 0 && C > 0);
+    BTS_CHECK_ARG((dtype == BTS_F32 || dtype == BTS_BF16) && vec_ok(dtype, C, stride, x));
+    const int V = dtype == BTS_F32 ? 4 : 8, CV = C / V, Cpad = (C + 7) / 8 * 8;
+    int bxl; dim3 grid;
+    pick_grid(M, CV, bxl, grid, 2048);
+    Shape2 s{M, CV};
+    hipStream_t st = (hipStream_t)stream;
+#define L_(TT, dummy) hipLaunchKernelGGL(bn_stats_partial_kernel<TT>, grid, dim3(256), 0, st, x, stride, s, bxl, (float*)workspace, Cpad)
+    DISPATCH_T(dtype, L_, 0);
+#undef L_
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float*)workspace, (int)grid.x, C,
+                       Cpad, (double)M, 0, mean, var);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_bn_prepare(const float* mean, const float* var, int C, long M, const float* gamma, const float* beta,
+                              float eps, float momentum, float* running_mean, float* running_var, float* invstd,
+                              float* scale, float* shift, bts_stream_t stream) {
+    BTS_CHECK_ARG(mean && var && scale && shift && C > 0 && M > 0);
+    BTS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+    hipLaunchKernelGGL(bn_prepare_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, mean, var, C, (double)M,
+                       gamma, beta, eps, momentum, running_mean, running_var, invstd, scale, shift);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_affine_act(const void* x, int x_dtype, int x_stride, void* y, int y_dtype, int y_stride, long M, int C,
+                              const float* scale, const float* shift, int act, bts_stream_t stream) {
+    BTS_CHECK_ARG(x && y && M > 0 && C > 0 && (act == BTS_ACT_NONE || act == BTS_ACT_RELU));
+    BTS_CHECK_ARG(x_dtype == y_dtype && (x_dtype == BTS_F32 || x_dtype == BTS_BF16));
+    BTS_CHECK_ARG(vec_ok(x_dtype, C, x_stride, x) && vec_ok(y_dtype, C, y_stride, y));
+    const int V = x_dtype == BTS_F32 ? 4 : 8, CV = C / V;
+    int bxl; dim3 grid;
+    pick_grid(M, CV, bxl, grid);
+    Shape2 s{M, CV};
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == BTS_F32) hipLaunchKernelGGL((affine_act_kernel<F32, F32>), grid, dim3(256), 0, st, x, x_stride, y, y_stride, s, bxl, scale, shift, act);
+    else hipLaunchKernelGGL((affine_act_kernel<BF16, BF16>), grid, dim3(256), 0, st, x, x_stride, y, y_stride, s, bxl, scale, shift, act);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_bn_bwd_reduce(const void* dy, int dy_stride, const void* x, int x_stride, int dtype, long M, int C,
+                                 const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
+                                 void* workspace, float* sums, bts_stream_t stream) {
+    BTS_CHECK_ARG(dy && x && mean && invstd && workspace && sums && M > 0 && C > 0);
+    BTS_CHECK_ARG((dtype == BTS_F32 || dtype == BTS_BF16) && vec_ok(dtype, C, x_stride, x) && vec_ok(dtype, C, dy_stride, dy));
+    const int V = dtype == BTS_F32 ? 4 : 8, CV = C / V, Cpad = (C + 7) / 8 * 8;
+    int bxl; dim3 grid;
+    pick_grid(M, CV, bxl, grid, 2048);
+    Shape2 s{M, CV};
+    hipStream_t st = (hipStream_t)stream;
+#define L_(TT, dummy) hipLaunchKernelGGL(bn_bwd_partial_kernel<TT>, grid, dim3(256), 0, st, dy, dy_stride, x, x_stride, s, bxl, mean, invstd, gamma, beta, relu, (float*)workspace, Cpad)
+    DISPATCH_T(dtype, L_, 0);
+#undef L_
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float*)workspace, (int)grid.x, C,
+                       Cpad, (double)M, 1, sums, sums + C);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_bn_bwd_apply(const void* dy, int dy_stride, const void* x, int x_stride, void* dx, int dx_stride, int dtype,
+                                long M, int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                int relu, const float* sums, int use_batch_stats, int accumulate, bts_stream_t stream) {
+    BTS_CHECK_ARG(dy && x && dx && mean && invstd && M > 0 && C > 0 && (sums || !use_batch_stats));
+    BTS_CHECK_ARG((dtype == BTS_F32 || dtype == BTS_BF16) && vec_ok(dtype, C, x_stride, x) && vec_ok(dtype, C, dy_stride, dy) &&
+                  vec_ok(dtype, C, dx_stride, dx));
+    const int V = dtype == BTS_F32 ? 4 : 8, CV = C / V;
+    int bxl; dim3 grid;
+    pick_grid(M, CV, bxl, grid);
+    Shape2 s{M, CV};
+    hipStream_t st = (hipStream_t)stream;
+#define L_(TT, dummy) hipLaunchKernelGGL(bn_bwd_apply_kernel<TT>, grid, dim3(256), 0, st, dy, dy_stride, x, x_stride, dx, dx_stride, s, bxl, mean, invstd, gamma, beta, relu, sums, C, use_batch_stats, accumulate)
+    DISPATCH_T(dtype, L_, 0);
+#undef L_
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_act_bwd(const void* dy, int dy_dtype, int dy_stride, const void* y, int y_dtype, int y_stride, void* dz,
+                           int dz_dtype, int dz_stride, long M, int C, int act, float y_scale, const float* y_scale_n,
+                           long pix_per_image, bts_stream_t stream) {
+    BTS_CHECK_ARG(dy && y && dz && M > 0 && C > 0 && act >= BTS_ACT_NONE && act <= BTS_ACT_RELU);
+    BTS_CHECK_ARG(y_scale_n == nullptr || pix_per_image > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const bool same = dy_dtype == y_dtype && y_dtype == dz_dtype;
+    if (same && (act == BTS_ACT_ELU || act == BTS_ACT_RELU) && vec_ok(dy_dtype, C, dy_stride, dy) &&
+        vec_ok(y_dtype, C, y_stride, y) && vec_ok(dz_dtype, C, dz_stride, dz)) {
+        const int V = dy_dtype == BTS_F32 ? 4 : 8, CV = C / V;
+        int bxl; dim3 grid;
+        pick_grid(M, CV, bxl, grid);
+        Shape2 s{M, CV};
+#define L_(TT, dummy) hipLaunchKernelGGL(act_bwd_vec_kernel<TT>, grid, dim3(256), 0, st, dy, dy_stride, y, y_stride, dz, dz_stride, s, bxl, act)
+        DISPATCH_T(dy_dtype, L_, 0);
+#undef L_
+    } else {
+        const int nb = flat_blocks(M * C);
+        const int key = (dy_dtype << 2) | (y_dtype << 1) | dz_dtype;
+#define L3(A, B, Cc) hipLaunchKernelGGL((act_bwd_kernel<A, B, Cc>), dim3(nb), dim3(256), 0, st, dy, dy_stride, y, y_stride, dz, dz_stride, M, C, act, y_scale, y_scale_n, pix_per_image)
+        switch (key) {
+            case 0: L3(F32, F32, F32); break;
+            case 1: L3(F32, F32, BF16); break;
+            case 2: L3(F32, BF16, F32); break;
+            case 3: L3(F32, BF16, BF16); break;
+            case 4: L3(BF16, F32, F32); break;
+            case 5: L3(BF16, F32, BF16); break;
+            case 6: L3(BF16, BF16, F32); break;
+            case 7: L3(BF16, BF16, BF16); break;
+            default: return BTS_ERR_ARG;
+        }
+#undef L3
+    }
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_add_to(const void* x, int x_dtype, int x_stride, void* y, int y_dtype, int y_stride, long M, int C,
+                          int accumulate, bts_stream_t stream) {
+    BTS_CHECK_ARG(x && y && M > 0 && C > 0);
+    const int nb = flat_blocks(M * C);
+    hipStream_t st = (hipStream_t)stream;
+    const int key = (x_dtype << 1) | y_dtype;
+#define L2(A, B) hipLaunchKernelGGL((add_to_kernel<A, B>), dim3(nb), dim3(256), 0, st, x, x_stride, y, y_stride, M, C, accumulate)
+    switch (key) {
+        case 0: L2(F32, F32); break;
+        case 1: L2(F32, BF16); break;
+        case 2: L2(BF16, F32); break;
+        case 3: L2(BF16, BF16); break;
+        default: return BTS_ERR_ARG;
+    }
+#undef L2
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_nchw_to_nhwc(const float* src, void* dst, int dst_dtype, int dst_stride, int N, int C, int H, int W, int relu,
+                                bts_stream_t stream) {
+    BTS_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && dst_stride >= C);
+    BTS_CHECK_ARG(dst_dtype == BTS_F32 || dst_dtype == BTS_BF16);
+    const int HW = H * W;
+    dim3 grid(ceil_div(HW, 32), ceil_div(C, 32), N);
+    if (dst_dtype == BTS_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<F32>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, dst_stride, C, HW, relu);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, dst_stride, C, HW, relu);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_nhwc_to_nchw(const void* src, int src_dtype, int src_stride, float* dst, const float* relu_src, int N, int C,
+                                int H, int W, bts_stream_t stream) {
+    BTS_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && src_stride >= C);
+    BTS_CHECK_ARG(src_dtype == BTS_F32 || src_dtype == BTS_BF16);
+    const int HW = H * W;
+    dim3 grid(ceil_div(HW, 32), ceil_div(C, 32), N);
+    if (src_dtype == BTS_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<F32>, grid, dim3(256), 0, (hipStream_t)stream, src, src_stride, dst, relu_src, C, HW);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, src, src_stride, dst, relu_src, C, HW);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_adamw_step(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                              const long* sizes, int n_tensors, long max_size, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, float bias_c1, float bias_c2, bts_stream_t stream) {
+    BTS_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && sizes && n_tensors > 0 && max_size > 0);
+    long bx = (max_size + 256 * 8 - 1) / (256 * 8);
+    if (bx > 512) bx = 512;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, params, grads,
+                       exp_avg, exp_avg_sq, sizes, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}

@@ -1,0 +1,479 @@
+// Local planar guidance (LPG) kernels and the silog loss for gfx950.
+//
+// All of these are HBM-bound streaming kernels: the design rule is "one
+// thread per coarse cell, loop over the k rows of its patch", so that a wavefront touches
+// 64 consecutive cells = 64*k consecutive output floats per row (full 128-byte lines), the
+// plane coefficients / transcendentals are evaluated once per cell, and the backward
+// k*k accumulation is thread-local (no atomics, no cross-lane traffic).
+//
+// Parity notes (bts.py:124-146): u, v are exact in f32 (k is a power of two); the
+// denominator is evaluated as ((n1*u) + (n2*v)) + n3 with every operation rounded on its
+// own (__fmul_rn/__fadd_rn, no FMA contraction), followed by IEEE division -- the reference's
+// exact operation order, so the LPG op is bit-identical to the PyTorch CPU path.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float lpg_offset(int r, int k) { return ((float)r - (float)(k - 1) * 0.5f) / (float)k; }
+
+__device__ __forceinline__ float lpg_eval(float n1, float n2, float n3, float n4, float u, float v, float div) {
+    const float den = __fadd_rn(__fadd_rn(__fmul_rn(n1, u), __fmul_rn(n2, v)), n3);
+    return (n4 / den) / div;
+}
+
+// ---- LPG op boundary: plane_eq [B][h][w][4] -> depth [B][hk][wk] ---------------------------
+template <int K>
+__global__ __launch_bounds__(256) void lpg_fwd_kernel(const float* __restrict__ eq, float* __restrict__ depth,
+                                                      int cells, int h, int w, float div) {
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= cells) return;
+    const int j = cell % w, bi = cell / w;          // bi = b*h + i
+    const f32x4_t e = *(const f32x4_t*)(eq + (size_t)cell * 4);
+    float* out = depth + ((size_t)bi * K) * ((size_t)w * K) + (size_t)j * K;
+    float u[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) u[c] = lpg_offset(c, K);
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        const float v = lpg_offset(r, K);
+        float o[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) o[c] = lpg_eval(e.x, e.y, e.z, e.w, u[c], v, div);
+        float* p = out + (size_t)r * w * K;
+        if (K >= 4) {
+#pragma unroll
+            for (int c = 0; c < K; c += 4) *(f32x4_t*)(p + c) = f32x4_t{o[c], o[c + 1], o[c + 2], o[c + 3]};
+        } else {
+            *(float2*)p = make_float2(o[0], o[1]);
+        }
+    }
+}
+
+// true gradient of out = n4 / (den * div)
+template <int K>
+__global__ __launch_bounds__(256) void lpg_bwd_kernel(const float* __restrict__ gdepth, const float* __restrict__ eq,
+                                                      float* __restrict__ geq, int cells, int h, int w, float div) {
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= cells) return;
+    const int j = cell % w, bi = cell / w;
+    const f32x4_t e = *(const f32x4_t*)(eq + (size_t)cell * 4);
+    const float* gp = gdepth + ((size_t)bi * K) * ((size_t)w * K) + (size_t)j * K;
+    float g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f;
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        const float v = lpg_offset(r, K);
+        float g[K];
+        const float* p = gp + (size_t)r * w * K;
+        if (K >= 4) {
+#pragma unroll
+            for (int c = 0; c < K; c += 4) {
+                const f32x4_t t = *(const f32x4_t*)(p + c);
+                g[c] = t.x; g[c + 1] = t.y; g[c + 2] = t.z; g[c + 3] = t.w;
+            }
+        } else {
+            const float2 t = *(const float2*)p;
+            g[0] = t.x; g[1] = t.y;
+        }
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+            const float u = lpg_offset(c, K);
+            const float den = __fadd_rn(__fadd_rn(__fmul_rn(e.x, u), __fmul_rn(e.y, v)), e.z);
+            const float inv = 1.f / (den * div);
+            const float gi = g[c] * inv;          // d out / d n4 * g
+            const float gq = -gi * (e.w / den);   // d out / d den * g
+            g4 += gi;
+            g1 += gq * u;
+            g2 += gq * v;
+            g3 += gq;
+        }
+    }
+    *(f32x4_t*)(geq + (size_t)cell * 4) = f32x4_t{g1, g2, g3, g4};
+}
+
+// ---- fused head ------------------------------------------------------------------------------
+struct Plane {
+    float n1, n2, n3, n4;        // normalised plane
+    float s0, s1, s2;            // sigmoids
+    float st, ct, sp, cp;        // sin/cos theta, phi
+    float m1, m2, m3, inv_norm;  // un-normalised normal and 1/max(norm, 1e-12)
+};
+
+__device__ __forceinline__ Plane plane_from_raw(float r0, float r1, float r2, float max_depth) {
+    Plane p;
+    p.s0 = act_sigmoid(r0); p.s1 = act_sigmoid(r1); p.s2 = act_sigmoid(r2);
+    const float theta = __fdiv_rn(__fmul_rn(p.s0, 3.14159274101257324f), 3.0f);   // sigmoid * math.pi / 3 (bts.py:113)
+    const float phi = __fmul_rn(__fmul_rn(p.s1, 3.14159274101257324f), 2.0f);     // sigmoid * math.pi * 2 (bts.py:114)
+    p.st = sinf(theta); p.ct = cosf(theta); p.sp = sinf(phi); p.cp = cosf(phi);
+    p.m1 = __fmul_rn(p.st, p.cp); p.m2 = __fmul_rn(p.st, p.sp); p.m3 = p.ct;     // bts.py:116-118
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(p.m1, p.m1), __fmul_rn(p.m2, p.m2)), __fmul_rn(p.m3, p.m3)));
+    const float d = fmaxf(nrm, 1e-12f);                                           // F.normalize eps (bts.py:224)
+    p.inv_norm = 1.f / d;
+    p.n1 = p.m1 / d; p.n2 = p.m2 / d; p.n3 = p.m3 / d;
+    p.n4 = __fmul_rn(p.s2, max_depth);                                            // bts.py:115
+    return p;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void lpg_head_fwd_kernel(const float* __restrict__ raw, int raw_stride,
+                                                           float* __restrict__ depth, float* __restrict__ eq_out,
+                                                           int cells, int h, int w, float max_depth) {
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= cells) return;
+    const int j = cell % w, bi = cell / w;
+    const float* rp = raw + (size_t)cell * raw_stride;
+    const Plane p = plane_from_raw(rp[0], rp[1], rp[2], max_depth);
+    if (eq_out) *(f32x4_t*)(eq_out + (size_t)cell * 4) = f32x4_t{p.n1, p.n2, p.n3, p.n4};
+    float* out = depth + ((size_t)bi * K) * ((size_t)w * K) + (size_t)j * K;
+    float u[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) u[c] = lpg_offset(c, K);
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        const float v = lpg_offset(r, K);
+        float o[K];
+#pragma unroll
+        for (int c = 0; c < K; ++c) o[c] = lpg_eval(p.n1, p.n2, p.n3, p.n4, u[c], v, max_depth);
+        float* q = out + (size_t)r * w * K;
+        if (K >= 4) {
+#pragma unroll
+            for (int c = 0; c < K; c += 4) *(f32x4_t*)(q + c) = f32x4_t{o[c], o[c + 1], o[c + 2], o[c + 3]};
+        } else {
+            *(float2*)q = make_float2(o[0], o[1]);
+        }
+    }
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(256) void lpg_head_bwd_kernel(const float* __restrict__ raw, int raw_stride,
+                                                           const float* __restrict__ gdepth, void* __restrict__ graw,
+                                                           int gstride, int gpad, int cells, int h, int w, float max_depth) {
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= cells) return;
+    const int j = cell % w, bi = cell / w;
+    const float* rp = raw + (size_t)cell * raw_stride;
+    const Plane p = plane_from_raw(rp[0], rp[1], rp[2], max_depth);
+    const float* gp = gdepth + ((size_t)bi * K) * ((size_t)w * K) + (size_t)j * K;
+    float g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f;
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        const float v = lpg_offset(r, K);
+        float g[K];
+        const float* q = gp + (size_t)r * w * K;
+        if (K >= 4) {
+#pragma unroll
+            for (int c = 0; c < K; c += 4) {
+                const f32x4_t t = *(const f32x4_t*)(q + c);
+                g[c] = t.x; g[c + 1] = t.y; g[c + 2] = t.z; g[c + 3] = t.w;
+            }
+        } else {
+            const float2 t = *(const float2*)q;
+            g[0] = t.x; g[1] = t.y;
+        }
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+            const float u = lpg_offset(c, K);
+            const float den = __fadd_rn(__fadd_rn(__fmul_rn(p.n1, u), __fmul_rn(p.n2, v)), p.n3);
+            const float gi = g[c] / (den * max_depth);
+            const float gq = -gi * (p.n4 / den);
+            g4 += gi; g1 += gq * u; g2 += gq * v; g3 += gq;
+        }
+    }
+    // through n = m / max(|m|, eps):  dm = (g - n * <n, g>) / |m|   (|m| > eps always: m is a unit vector up to rounding)
+    const float dot = g1 * p.n1 + g2 * p.n2 + g3 * p.n3;
+    const float gm1 = (g1 - p.n1 * dot) * p.inv_norm;
+    const float gm2 = (g2 - p.n2 * dot) * p.inv_norm;
+    const float gm3 = (g3 - p.n3 * dot) * p.inv_norm;
+    // m1 = st*cp, m2 = st*sp, m3 = ct
+    const float gtheta = gm1 * p.ct * p.cp + gm2 * p.ct * p.sp - gm3 * p.st;
+    const float gphi = -gm1 * p.st * p.sp + gm2 * p.st * p.cp;
+    const float PI = 3.14159274101257324f;
+    const float gr0 = gtheta * (PI / 3.0f) * p.s0 * (1.f - p.s0);
+    const float gr1 = gphi * (PI * 2.0f) * p.s1 * (1.f - p.s1);
+    const float gr2 = g4 * max_depth * p.s2 * (1.f - p.s2);
+    const size_t o = (size_t)cell * gstride;
+    T::st(graw, o + 0, gr0); T::st(graw, o + 1, gr1); T::st(graw, o + 2, gr2);
+    for (int c = 3; c < gpad; ++c) T::st(graw, o + c, 0.f);
+}
+
+// ---- depth-map slot pack / unpack -------------------------------------------------------------
+struct MapsK {
+    const float* src[4];
+    float* gsrc[4];
+    int ds[4];
+    int n_src;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_maps_kernel(const MapsK a, void* __restrict__ dst, int stride, int C, long M,
+                                                        int H, int W) {
+    for (long m = blockIdx.x * 256l + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+        const int x = (int)(m % W);
+        const long ny = m / W;
+        const int y = (int)(ny % H);
+        const long n = ny / H;
+        float v[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) v[s] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (s < a.n_src) {
+                const int d = a.ds[s];
+                v[s] = a.src[s][((size_t)n * H * d + (size_t)y * d) * ((size_t)W * d) + (size_t)x * d];
+            }
+#pragma unroll
+        for (int q = 0; q < 8 / T::kVec; ++q) {
+            if (q * T::kVec < C)
+                *(u32x4_t*)((char*)dst + ((size_t)m * stride + q * T::kVec) * T::kBytes) = T::pack(v + q * T::kVec);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_maps_kernel(const MapsK a, const void* __restrict__ gdst, int stride, long M,
+                                                          int H, int W) {
+    for (long m = blockIdx.x * 256l + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+        const int x = (int)(m % W);
+        const long ny = m / W;
+        const int y = (int)(ny % H);
+        const long n = ny / H;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (s < a.n_src) {
+                const int d = a.ds[s];
+                float* p = a.gsrc[s] + ((size_t)n * H * d + (size_t)y * d) * ((size_t)W * d) + (size_t)x * d;
+                *p += T::ld(gdst, (size_t)m * stride + s);
+            }
+    }
+}
+
+// ---- silog -------------------------------------------------------------------------------------
+constexpr int SILOG_MAX_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void silog_partial_kernel(const float* __restrict__ est, const float* __restrict__ gt,
+                                                            const uint8_t* __restrict__ mask, float thr, long n,
+                                                            double* __restrict__ ws) {
+    float s1 = 0.f, s2 = 0.f, cnt = 0.f;
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * 256l + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4_t e = ((const f32x4_t*)est)[i];
+        const f32x4_t g = ((const f32x4_t*)gt)[i];
+        uint32_t mk = 0x01010101u;
+        if (mask) mk = ((const uint32_t*)mask)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool on = mask ? ((mk >> (8 * k)) & 0xff) != 0 : g[k] > thr;
+            if (on) {
+                const float d = logf(e[k]) - logf(g[k]);
+                s1 += d; s2 += d * d; cnt += 1.f;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {   // tail
+        const long i = (n4 << 2) + threadIdx.x;
+        const bool on = mask ? mask[i] != 0 : gt[i] > thr;
+        if (on) {
+            const float d = logf(est[i]) - logf(gt[i]);
+            s1 += d; s2 += d * d; cnt += 1.f;
+        }
+    }
+    __shared__ double sh[3][4];
+    double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2), dc = wave_sum_d((double)cnt);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][wv] = d1; sh[1][wv] = d2; sh[2][wv] = dc; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const double t = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+        ws[(size_t)blockIdx.x * 3 + threadIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void silog_final_kernel(const double* __restrict__ ws, int nblocks, float vf,
+                                                          double* __restrict__ stats, float* __restrict__ loss) {
+    double a[3] = {0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+        for (int k = 0; k < 3; ++k) a[k] += ws[(size_t)b * 3 + k];
+    __shared__ double sh[3][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = 0; k < 3; ++k) {
+        const double t = wave_sum_d(a[k]);
+        if (lane == 0) sh[k][wv] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double s1 = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        const double s2 = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        const double c = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
+        stats[0] = s1; stats[1] = s2; stats[2] = c;
+        const double mean = s1 / c;
+        loss[0] = (float)(sqrt(s2 / c - (double)vf * mean * mean) * 10.0);
+    }
+}
+
+__global__ __launch_bounds__(256) void silog_bwd_kernel(const float* __restrict__ est, const float* __restrict__ gt,
+                                                        const uint8_t* __restrict__ mask, float thr, long n, float vf,
+                                                        const double* __restrict__ stats, const float* __restrict__ loss,
+                                                        const float* __restrict__ gloss, float* __restrict__ gest) {
+    const double c = stats[2];
+    const float mean = (float)(stats[0] / c);
+    // d loss / d d_i = (100 / loss) * (d_i - vf * mean) / count
+    const float coef = gloss[0] * (float)(100.0 / ((double)loss[0] * c));
+    const float vm = vf * mean;
+    for (long i = blockIdx.x * 256l + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float e = est[i], g = gt[i];
+        const bool on = mask ? mask[i] != 0 : g > thr;
+        gest[i] = on ? coef * ((logf(e) - logf(g)) - vm) / e : 0.f;
+    }
+}
+
+template <int K>
+int lpg_fwd_launch(const float* eq, float* depth, int cells, int h, int w, float div, hipStream_t st) {
+    hipLaunchKernelGGL(lpg_fwd_kernel<K>, dim3(ceil_div(cells, 256)), dim3(256), 0, st, eq, depth, cells, h, w, div);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+template <int K>
+int lpg_bwd_launch(const float* g, const float* eq, float* geq, int cells, int h, int w, float div, hipStream_t st) {
+    hipLaunchKernelGGL(lpg_bwd_kernel<K>, dim3(ceil_div(cells, 256)), dim3(256), 0, st, g, eq, geq, cells, h, w, div);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+}  // namespace
+
+#define LPG_ARGS_OK(p1, p2, B, h, w, k) \
+    ((p1) && (p2) && (B) > 0 && (h) > 0 && (w) > 0 && ((k) == 1 || (k) == 2 || (k) == 4 || (k) == 8) && (long)(B) * (h) * (w) < (1l << 31))
+
+extern "C" int bts_abi_version(void) { return BTS_AMD_ABI_VERSION; }
+extern "C" int bts_current_device(void) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    return dev;
+}
+
+extern "C" int bts_lpg_fwd(const float* plane_eq, const float* focal, float* depth, int B, int h, int w, int k,
+                           float depth_div, bts_stream_t stream) {
+    (void)focal;  // ignored, as in the reference (local_planar_guidance.cu:56, bts.py:132)
+    BTS_CHECK_ARG(LPG_ARGS_OK(plane_eq, depth, B, h, w, k) && k >= 2 && depth_div != 0.f);
+    BTS_CHECK_ARG(((uintptr_t)plane_eq & 15) == 0 && ((uintptr_t)depth & 15) == 0);
+    const int cells = B * h * w;
+    hipStream_t st = (hipStream_t)stream;
+    switch (k) {
+        case 8: return lpg_fwd_launch<8>(plane_eq, depth, cells, h, w, depth_div, st);
+        case 4: return lpg_fwd_launch<4>(plane_eq, depth, cells, h, w, depth_div, st);
+        default: return lpg_fwd_launch<2>(plane_eq, depth, cells, h, w, depth_div, st);
+    }
+}
+
+extern "C" int bts_lpg_bwd(const float* grad_depth, const float* plane_eq, const float* focal, float* grad_plane_eq,
+                           int B, int h, int w, int k, float depth_div, bts_stream_t stream) {
+    (void)focal;
+    BTS_CHECK_ARG(LPG_ARGS_OK(grad_depth, plane_eq, B, h, w, k) && grad_plane_eq && k >= 2 && depth_div != 0.f);
+    BTS_CHECK_ARG(((uintptr_t)plane_eq & 15) == 0 && ((uintptr_t)grad_depth & 15) == 0 && ((uintptr_t)grad_plane_eq & 15) == 0);
+    const int cells = B * h * w;
+    hipStream_t st = (hipStream_t)stream;
+    switch (k) {
+        case 8: return lpg_bwd_launch<8>(grad_depth, plane_eq, grad_plane_eq, cells, h, w, depth_div, st);
+        case 4: return lpg_bwd_launch<4>(grad_depth, plane_eq, grad_plane_eq, cells, h, w, depth_div, st);
+        default: return lpg_bwd_launch<2>(grad_depth, plane_eq, grad_plane_eq, cells, h, w, depth_div, st);
+    }
+}
+
+extern "C" int bts_lpg_head_fwd(const float* raw, int raw_stride, float* depth, float* plane_eq, int B, int h, int w,
+                                int k, float max_depth, bts_stream_t stream) {
+    BTS_CHECK_ARG(LPG_ARGS_OK(raw, depth, B, h, w, k) && k >= 2 && raw_stride >= 3 && max_depth > 0.f);
+    BTS_CHECK_ARG(((uintptr_t)depth & 15) == 0 && ((uintptr_t)plane_eq & 15) == 0);
+    const int cells = B * h * w;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g(ceil_div(cells, 256)), b(256);
+    switch (k) {
+        case 8: hipLaunchKernelGGL(lpg_head_fwd_kernel<8>, g, b, 0, st, raw, raw_stride, depth, plane_eq, cells, h, w, max_depth); break;
+        case 4: hipLaunchKernelGGL(lpg_head_fwd_kernel<4>, g, b, 0, st, raw, raw_stride, depth, plane_eq, cells, h, w, max_depth); break;
+        default: hipLaunchKernelGGL(lpg_head_fwd_kernel<2>, g, b, 0, st, raw, raw_stride, depth, plane_eq, cells, h, w, max_depth); break;
+    }
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_lpg_head_bwd(const float* raw, int raw_stride, const float* grad_depth, void* grad_raw, int grad_dtype,
+                                int grad_stride, int grad_pad, int B, int h, int w, int k, float max_depth,
+                                bts_stream_t stream) {
+    BTS_CHECK_ARG(LPG_ARGS_OK(raw, grad_depth, B, h, w, k) && grad_raw && k >= 2 && raw_stride >= 3 && max_depth > 0.f);
+    BTS_CHECK_ARG((grad_dtype == BTS_F32 || grad_dtype == BTS_BF16) && grad_pad >= 3 && grad_stride >= grad_pad);
+    BTS_CHECK_ARG(((uintptr_t)grad_depth & 15) == 0);
+    const int cells = B * h * w;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g(ceil_div(cells, 256)), b(256);
+#define HEAD_BWD(TT, KK) hipLaunchKernelGGL((lpg_head_bwd_kernel<TT, KK>), g, b, 0, st, raw, raw_stride, grad_depth, grad_raw, grad_stride, grad_pad, cells, h, w, max_depth)
+    if (grad_dtype == BTS_F32) {
+        if (k == 8) HEAD_BWD(F32, 8); else if (k == 4) HEAD_BWD(F32, 4); else HEAD_BWD(F32, 2);
+    } else {
+        if (k == 8) HEAD_BWD(BF16, 8); else if (k == 4) HEAD_BWD(BF16, 4); else HEAD_BWD(BF16, 2);
+    }
+#undef HEAD_BWD
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_pack_maps(const float* const* src, const int* ds, int n_src, void* dst, int dst_dtype, int dst_stride,
+                             int C, int N, int H, int W, bts_stream_t stream) {
+    BTS_CHECK_ARG(src && ds && dst && n_src >= 1 && n_src <= 4 && N > 0 && H > 0 && W > 0);
+    BTS_CHECK_ARG(dst_dtype == BTS_F32 || dst_dtype == BTS_BF16);
+    const int VEC = dst_dtype == BTS_F32 ? 4 : 8;
+    BTS_CHECK_ARG(C % VEC == 0 && C >= n_src && C <= 8 && dst_stride % VEC == 0 && dst_stride >= C && ((uintptr_t)dst & 15) == 0);
+    MapsK a{};
+    a.n_src = n_src;
+    for (int s = 0; s < n_src; ++s) { BTS_CHECK_ARG(src[s] && ds[s] >= 1); a.src[s] = src[s]; a.ds[s] = ds[s]; }
+    const long M = (long)N * H * W;
+    const int blocks = (int)((M + 255) / 256 > 8192 ? 8192 : (M + 255) / 256);
+    if (dst_dtype == BTS_F32) hipLaunchKernelGGL(pack_maps_kernel<F32>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, dst, dst_stride, C, M, H, W);
+    else hipLaunchKernelGGL(pack_maps_kernel<BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, dst, dst_stride, C, M, H, W);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_unpack_maps(const void* gdst, int dst_dtype, int dst_stride, float* const* gsrc, const int* ds, int n_src,
+                               int N, int H, int W, bts_stream_t stream) {
+    BTS_CHECK_ARG(gdst && gsrc && ds && n_src >= 1 && n_src <= 4 && N > 0 && H > 0 && W > 0);
+    BTS_CHECK_ARG(dst_dtype == BTS_F32 || dst_dtype == BTS_BF16);
+    MapsK a{};
+    a.n_src = n_src;
+    for (int s = 0; s < n_src; ++s) { BTS_CHECK_ARG(gsrc[s] && ds[s] >= 1); a.gsrc[s] = gsrc[s]; a.ds[s] = ds[s]; }
+    const long M = (long)N * H * W;
+    const int blocks = (int)((M + 255) / 256 > 8192 ? 8192 : (M + 255) / 256);
+    if (dst_dtype == BTS_F32) hipLaunchKernelGGL(unpack_maps_kernel<F32>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, gdst, dst_stride, M, H, W);
+    else hipLaunchKernelGGL(unpack_maps_kernel<BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, gdst, dst_stride, M, H, W);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+static int silog_blocks(long n) {
+    long b = (n / 4 + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > SILOG_MAX_BLOCKS) b = SILOG_MAX_BLOCKS;
+    return (int)b;
+}
+extern "C" long bts_silog_workspace_bytes(long n) { return (long)silog_blocks(n) * 3 * sizeof(double); }
+
+extern "C" int bts_silog_fwd(const float* est, const float* gt, const uint8_t* mask, float thr, long n, float vf,
+                             void* workspace, double* stats_out, float* loss_out, bts_stream_t stream) {
+    BTS_CHECK_ARG(est && gt && workspace && stats_out && loss_out && n > 0);
+    BTS_CHECK_ARG(((uintptr_t)est & 15) == 0 && ((uintptr_t)gt & 15) == 0 && ((uintptr_t)workspace & 7) == 0);
+    BTS_CHECK_ARG(mask == nullptr || ((uintptr_t)mask & 3) == 0);
+    const int nb = silog_blocks(n);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(silog_partial_kernel, dim3(nb), dim3(256), 0, st, est, gt, mask, thr, n, (double*)workspace);
+    hipLaunchKernelGGL(silog_final_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, nb, vf, stats_out, loss_out);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_silog_bwd(const float* est, const float* gt, const uint8_t* mask, float thr, long n, float vf,
+                             const double* stats, const float* loss, const float* grad_loss, float* grad_est,
+                             bts_stream_t stream) {
+    BTS_CHECK_ARG(est && gt && stats && loss && grad_loss && grad_est && n > 0);
+    const int nb = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(silog_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, est, gt, mask, thr, n, vf, stats, loss,
+                       grad_loss, grad_est);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}

@@ -1,0 +1,309 @@
+"""Explicit forward/backward executor of the BTS decoder on the HIP kernels.
+
+This is the replacement for the body of ``bts.forward`` (pytorch/bts.py:196-266) and for what
+PyTorch autograd would record for it.  Instead of a tracing compiler or ~700 eager ATen
+launches, the decoder is a short static schedule of C-ABI calls; the forward pass appends
+one closure per op to a tape and the backward pass replays the tape in reverse, accumulating
+gradients directly into per-tensor gradient buffers (the data-gradient kernels have a
+read-add-write epilogue, so fan-out never needs a separate add pass).
+
+Activations are NHWC in ``dtype`` (f32 for parity, bf16 for throughput); parameters, BatchNorm
+statistics, LPG heads and the five outputs are f32.  torch.cat never happens: every conv reads
+its concatenated input as a list of segments.
+"""
+import torch
+
+from . import ops
+from ._lib import ACT_ELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BtsAmdError
+from .conv import ConvLayer
+from .ops import pad_to, vec_of
+
+KITTI_FOCAL_REF = 715.0873  # bts.py:264
+BN_MOMENTUM = 0.01          # bts.py:154 etc.
+
+
+def reduction_specs(c_in, c_out, is_final):
+    """(child name, cin, cout) of the 1x1 convs reduction_1x1.__init__ builds (bts.py:91-108)."""
+    out = []
+    while c_out >= 4:
+        if c_out < 8:
+            out.append(("final" if is_final else "plane_params", c_in, 1 if is_final else 3))
+            break
+        out.append(("inter_%d_%d" % (c_in, c_out), c_in, c_out))
+        c_in, c_out = c_out, c_out // 2
+    return out
+
+
+class Act:
+    """An activation (NHWC tensor, or a single-channel f32 map [N,H,W]) and its gradient buffer."""
+    __slots__ = ("t", "g", "stats")
+
+    def __init__(self, t):
+        self.t, self.g, self.stats = t, None, None
+
+
+class DecoderPlan:
+    """Static description of the decoder for given encoder channels (bts.__init__, bts.py:149-194)."""
+
+    def __init__(self, feat, nf):
+        for c in feat:
+            if c % 8:
+                raise BtsAmdError("encoder feature channels must be multiples of 8, got %s" % (feat,))
+        if nf % 128 or nf < 128:
+            raise BtsAmdError("bts_size must be a multiple of 128")
+        self.feat, self.nf = list(feat), nf
+        L = {}
+
+        def add(name, cout, segs, kk, dil=1, up=False):
+            L[name] = ConvLayer(name, cout, segs, kk, dil, up)
+
+        add("upconv5.conv", nf, [feat[4]], 9, up=True)
+        add("conv5.0", nf, [nf, feat[3]], 9)
+        add("upconv4.conv", nf // 2, [nf], 9, up=True)
+        add("conv4.0", nf // 2, [nf // 2, feat[2]], 9)
+        cin = {3: nf // 2, 6: nf // 2 + nf // 4 + feat[2], 12: nf + feat[2], 18: nf + nf // 4 + feat[2],
+               24: nf + nf // 2 + feat[2]}
+        for d in (3, 6, 12, 18, 24):
+            add("daspp_%d.atrous_conv.aconv_sequence.1" % d, nf // 2, [cin[d]], 1)
+            add("daspp_%d.atrous_conv.aconv_sequence.4" % d, nf // 4, [nf // 2], 9, dil=d)
+        self.daspp_cin = cin
+        add("daspp_conv.0", nf // 4, [nf // 2] + [nf // 4] * 5, 9)
+        self.reduc = {}
+        for name, ci, co, fin in (("reduc8x8", nf // 4, nf // 4, False), ("reduc4x4", nf // 4, nf // 8, False),
+                                  ("reduc2x2", nf // 8, nf // 16, False), ("reduc1x1", nf // 16, nf // 32, True)):
+            chain = []
+            for child, a, b in reduction_specs(ci, co, fin):
+                key = "%s.reduc.%s" % (name, child + (".0" if child != "plane_params" else ""))
+                add(key, b, [a], 1)
+                chain.append(key)
+            self.reduc[name] = chain
+        add("upconv3.conv", nf // 4, [nf // 4], 9, up=True)
+        add("conv3.0", nf // 4, [nf // 4, feat[1], 1], 9)
+        add("upconv2.conv", nf // 8, [nf // 4], 9, up=True)
+        add("conv2.0", nf // 8, [nf // 8, feat[0], 1], 9)
+        add("upconv1.conv", nf // 16, [nf // 8], 9, up=True)
+        add("conv1.0", nf // 16, [nf // 16, 4], 9)
+        add("get_depth.0", 1, [nf // 16], 9)
+        self.layers = L
+
+
+class DecoderRun:
+    """One forward (and optionally backward) pass."""
+
+    def __init__(self, plan, P, bn_training, max_depth, dataset, dtype, record):
+        self.plan, self.P, self.bn_training = plan, P, bn_training
+        self.max_depth, self.dataset, self.dtype, self.record = float(max_depth), dataset, dtype, record
+        self.v = vec_of(dtype)
+        self.tape, self.grads = [], {}
+        self.feat_acts, self.feat_src = [], []
+        self.outs = None
+
+    # ---- ops -------------------------------------------------------------------------------
+    def feature(self, f, relu=False):
+        src = f.detach()
+        if src.dtype != torch.float32 or not src.is_contiguous():
+            src = src.float().contiguous()
+        a = Act(ops.nchw_to_nhwc(src, self.dtype, relu))
+        self.feat_acts.append(a)
+        self.feat_src.append((src if relu else None, f.shape[1]))
+        return a
+
+    def conv(self, name, segs, act, out_map=False, out_f32=False, out_scale=1.0, out_scale_n=None):
+        L = self.plan.layers[name]
+        w = self.P[name + ".weight"]
+        wp = L.pack_fwd(w, self.dtype)
+        x = [s.t for s in segs]
+        N, Hx, Wx, _ = x[0].shape
+        Ho, Wo = (2 * Hx, 2 * Wx) if L.up else (Hx, Wx)
+        dev = x[0].device
+        if out_map:
+            out = torch.empty((N, Ho, Wo), dtype=torch.float32, device=dev)
+        else:
+            odt = torch.float32 if out_f32 else self.dtype
+            cp = pad_to(L.cout, vec_of(odt))
+            out = (torch.zeros if cp != L.cout else torch.empty)((N, Ho, Wo, cp), dtype=odt, device=dev)
+        L.forward(x, wp, out, act, out_scale, out_scale_n)
+        y = Act(out)
+        if self.record:
+            def bwd():
+                if y.g is None:
+                    return
+                if out_map:
+                    dz = ops.act_bwd(y.g, y.t, act, out_dtype=self.dtype, out_channels=self.v, y_scale=out_scale,
+                                     y_scale_n=out_scale_n)
+                elif act == ACT_NONE:
+                    dz = y.g
+                else:
+                    dz = ops.act_bwd(y.g, y.t, act, out=y.g)
+                for i, s in enumerate(segs):
+                    wd = L.pack_dgrad(w, self.dtype, i)
+                    acc = s.g is not None
+                    if not acc:
+                        s.g = torch.empty(s.t.shape, dtype=self.dtype, device=dev)
+                    L.dgrad(dz, wd, i, s.g, acc)
+                self.grads[name + ".weight"] = L.wgrad(x, dz)
+            self.tape.append(bwd)
+        return y
+
+    def _bn_params(self, prefix, c0, c1):
+        P = self.P
+        sl = slice(c0, c1)
+        return (P[prefix + ".weight"][sl], P[prefix + ".bias"][sl], P[prefix + ".running_mean"][sl],
+                P[prefix + ".running_var"][sl])
+
+    def _bn_seg(self, x, prefix, eps, relu, c0, out):
+        """BatchNorm (+ReLU) of one tensor against channels [c0, c0+C) of BN `prefix`; returns saved state."""
+        Cc = x.t.shape[3]
+        g, b, rm, rv = self._bn_params(prefix, c0, c0 + Cc)
+        M = ops.npix(x.t)
+        train = self.bn_training[prefix]
+        if train:
+            if x.stats is None:
+                x.stats = ops.bn_stats(x.t)      # shared by every BN that sees this tensor
+            mean, var = x.stats
+            invstd, scale, shift = ops.bn_prepare(mean, var, M, g, b, eps, BN_MOMENTUM, rm, rv)
+        else:
+            mean = rm
+            invstd, scale, shift = ops.bn_prepare(rm, rv, M, g, b, eps)
+        ops.affine_act(x.t, scale, shift, ACT_RELU if relu else ACT_NONE, out=out)
+        return mean, invstd, g, b, train
+
+    def bn(self, x, prefix, eps, relu=False):
+        return self.bn_cat([x], prefix, eps, relu)
+
+    def bn_cat(self, segs, prefix, eps, relu):
+        """BN(+ReLU) over the channel concatenation of `segs`, materialised as one tensor."""
+        N, H, W, _ = segs[0].t.shape
+        ctot = sum(s.t.shape[3] for s in segs)
+        out = torch.empty((N, H, W, ctot), dtype=self.dtype, device=segs[0].t.device)
+        saved, c0 = [], 0
+        for s in segs:
+            Cc = s.t.shape[3]
+            saved.append((s, c0, self._bn_seg(s, prefix, eps, relu, c0, out[..., c0:c0 + Cc])))
+            c0 += Cc
+        if any(st[4] for _, _, st in saved):
+            nbt = self.P.get(prefix + ".num_batches_tracked")
+            if nbt is not None:
+                nbt.add_(1)
+        y = Act(out)
+        if self.record:
+            def bwd():
+                if y.g is None:
+                    return
+                dgs, dbs = [], []
+                for s, c0, (mean, invstd, g, b, train) in saved:
+                    Cc = s.t.shape[3]
+                    acc = s.g is not None
+                    if not acc:
+                        s.g = torch.empty(s.t.shape, dtype=self.dtype, device=s.t.device)
+                    db, dg = ops.bn_bwd(y.g[..., c0:c0 + Cc], s.t, mean, invstd, g, b, relu, s.g, acc, train)
+                    dgs.append(dg)
+                    dbs.append(db)
+                self.grads[prefix + ".weight"] = torch.cat(dgs) if len(dgs) > 1 else dgs[0]
+                self.grads[prefix + ".bias"] = torch.cat(dbs) if len(dbs) > 1 else dbs[0]
+            self.tape.append(bwd)
+        return y
+
+    def relu(self, x):
+        y = Act(ops.affine_act(x.t, None, None, ACT_RELU))
+        if self.record:
+            def bwd():
+                if y.g is None:
+                    return
+                if x.g is None:
+                    x.g = ops.act_bwd(y.g, y.t, ACT_RELU)
+                else:
+                    ops.add_to(ops.act_bwd(y.g, y.t, ACT_RELU, out=y.g), x.g, True)
+            self.tape.append(bwd)
+        return y
+
+    def head(self, raw, k):
+        d = Act(ops.lpg_head_fwd(raw.t, k, self.max_depth))
+        if self.record:
+            def bwd():
+                if d.g is None:
+                    return
+                raw.g = ops.lpg_head_bwd(raw.t, d.g, k, self.max_depth, self.dtype, self.v)
+            self.tape.append(bwd)
+        return d
+
+    def slots(self, maps, ds, N, H, W):
+        y = Act(ops.pack_maps([m.t for m in maps], ds, N, H, W, self.dtype))
+        if self.record:
+            def bwd():
+                if y.g is None:
+                    return
+                for m in maps:
+                    if m.g is None:
+                        m.g = torch.zeros_like(m.t)
+                ops.unpack_maps(y.g, [m.g for m in maps], ds)
+            self.tape.append(bwd)
+        return y
+
+    def chain(self, name, x):
+        keys = self.plan.reduc[name]
+        for key in keys[:-1]:
+            x = self.conv(key, [x], ACT_ELU)                       # bts.py:101-105
+        if name == "reduc1x1":
+            return self.conv(keys[-1], [x], ACT_SIGMOID, out_map=True)   # bts.py:93-96
+        return self.conv(keys[-1], [x], ACT_NONE, out_f32=True)          # bts.py:98-99 (raw plane params)
+
+    def atrous(self, d, x):
+        """atrous_conv minus first_bn (bts.py:57-62): x is already BN'd/ReLU'd."""
+        p = "daspp_%d.atrous_conv.aconv_sequence" % d
+        a = self.conv(p + ".1", [x], ACT_NONE)
+        a = self.bn(a, p + ".2", 1e-5, relu=True)                 # default eps (bts.py:60)
+        return self.conv(p + ".4", [a], ACT_NONE)
+
+    # ---- schedule (bts.forward, bts.py:196-266) ------------------------------------------------
+    def forward(self, features, focal):
+        f = features
+        N, _, H2, W2 = f[0].shape
+        H, W = 2 * H2, 2 * W2
+        s0, s1, s2, s3 = (self.feature(f[i]) for i in range(4))
+        dense = self.feature(f[4], relu=True)                               # :198
+        u5 = self.bn(self.conv("upconv5.conv", [dense], ACT_ELU), "bn5", 1.1e-5)      # :199-200
+        i5 = self.conv("conv5.0", [u5, s3], ACT_ELU)                        # :201-202
+        u4 = self.bn(self.conv("upconv4.conv", [i5], ACT_ELU), "bn4", 1.1e-5)        # :204-205
+        i4 = self.bn(self.conv("conv4.0", [u4, s2], ACT_ELU), "bn4_2", 1.1e-5)       # :206-208
+        d3 = self.atrous(3, self.relu(i4))                                  # :210 (no first_bn)
+        cat = [u4, s2, d3]
+        dk = {3: d3}
+        for d in (6, 12, 18, 24):                                           # :211-218
+            n = self.bn_cat(cat, "daspp_%d.atrous_conv.first_bn" % d, 1.1e-5, relu=True)
+            dk[d] = self.atrous(d, n)
+            cat = cat + [dk[d]]
+        df = self.conv("daspp_conv.0", [i4, dk[3], dk[6], dk[12], dk[18], dk[24]], ACT_ELU)   # :219-220
+
+        d8 = self.head(self.chain("reduc8x8", df), 8)                       # :222-228
+        u3 = self.bn(self.conv("upconv3.conv", [df], ACT_ELU), "bn3", 1.1e-5)        # :231-232
+        i3 = self.conv("conv3.0", [u3, s1, self.slots([d8], [4], N, H // 4, W // 4)], ACT_ELU)   # :229, 233-234
+        d4 = self.head(self.chain("reduc4x4", i3), 4)                       # :236-242
+        u2 = self.bn(self.conv("upconv2.conv", [i3], ACT_ELU), "bn2", 1.1e-5)        # :245-246
+        i2 = self.conv("conv2.0", [u2, s0, self.slots([d4], [2], N, H // 2, W // 2)], ACT_ELU)   # :243, 247-248
+        d2 = self.head(self.chain("reduc2x2", i2), 2)                       # :250-256
+        u1 = self.conv("upconv1.conv", [i2], ACT_ELU)                       # :258
+        r1 = self.chain("reduc1x1", u1)                                     # :259
+        i1 = self.conv("conv1.0", [u1, self.slots([r1, d2, d4, d8], [1, 1, 1, 1], N, H, W)], ACT_ELU)   # :260-261
+        scale_n = None
+        if self.dataset == "kitti":                                         # :263-264
+            scale_n = (focal.detach().to(device=i1.t.device, dtype=torch.float32) / KITTI_FOCAL_REF).contiguous()
+        depth = self.conv("get_depth.0", [i1], ACT_SIGMOID, out_map=True, out_scale=self.max_depth, out_scale_n=scale_n)
+        self.outs = [d8, d4, d2, r1, depth]
+        return tuple(o.t.view(N, 1, H, W) for o in self.outs)
+
+    def backward(self, grad_outs):
+        if not self.record:
+            raise BtsAmdError("backward() on a decoder pass that was run without recording")
+        for o, g in zip(self.outs, grad_outs):
+            if g is not None:
+                # the LPG maps also receive gradient through conv1/conv3/conv2: own the buffer
+                o.g = g.reshape(o.t.shape).to(torch.float32).clone(memory_format=torch.contiguous_format)
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+        gfeats = []
+        for a, (relu_src, Cc) in zip(self.feat_acts, self.feat_src):
+            gfeats.append(None if a.g is None else ops.nhwc_to_nchw(a.g, Cc, relu_src))
+        # feature() was called for skips 0..3 then the dense map
+        return gfeats, self.grads

@@ -1,0 +1,203 @@
+"""Tensor-level wrappers over the libbts_amd.so C ABI (no autograd here).
+
+Activations are NHWC torch tensors ``[N, H, W, C]`` (f32 or bf16) whose last dim is contiguous
+and whose pixels are evenly strided, so a channel slice ``t[..., a:b]`` of a wider buffer is a
+valid argument (pointer + pixel stride).  Every function enqueues on the current PyTorch HIP
+stream and raises ``BtsAmdError`` on any failure -- there is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_ELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BtsAmdError, call, dtype_code, stream_ptr  # noqa: F401
+
+
+def vec_of(dtype):
+    return 4 if dtype == torch.float32 else 8
+
+
+def pad_to(c, v):
+    return (c + v - 1) // v * v
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def pix_stride(t):
+    """Pixel stride (elements) of an NHWC tensor/slice; validates the layout."""
+    if t.dim() != 4 or t.stride(3) != 1:
+        raise BtsAmdError("expected NHWC tensor with contiguous channels, got strides %s" % (t.stride(),))
+    s = t.stride(2)
+    N, H, W, _ = t.shape
+    if (H > 1 and t.stride(1) != W * s) or (N > 1 and t.stride(0) != H * W * s):
+        raise BtsAmdError("NHWC tensor pixels are not evenly strided: %s %s" % (t.shape, t.stride()))
+    return s
+
+
+def npix(t):
+    return t.shape[0] * t.shape[1] * t.shape[2]
+
+
+# ---------------------------------------------------------------------------------------------
+# LPG op boundary (TF-op layout): plane_eq [B,h,w,4] f32 -> depth [B,h*k,w*k] f32
+# ---------------------------------------------------------------------------------------------
+def lpg_fwd(plane_eq, k, depth_div=1.0, focal=None):
+    _lib.require_gpu(plane_eq)
+    B, h, w, four = plane_eq.shape
+    assert four == 4 and plane_eq.dtype == torch.float32 and plane_eq.is_contiguous()
+    out = torch.empty((B, h * k, w * k), dtype=torch.float32, device=plane_eq.device)
+    call("bts_lpg_fwd", _p(plane_eq), _p(focal), _p(out), B, h, w, k, float(depth_div), stream_ptr())
+    return out
+
+
+def lpg_bwd(grad_depth, plane_eq, k, depth_div=1.0, focal=None):
+    B, h, w, _ = plane_eq.shape
+    grad_depth = grad_depth.contiguous()
+    g = torch.empty_like(plane_eq)
+    call("bts_lpg_bwd", _p(grad_depth), _p(plane_eq), _p(focal), _p(g), B, h, w, k, float(depth_div), stream_ptr())
+    return g
+
+
+def lpg_head_fwd(raw, k, max_depth, want_plane=False):
+    """raw [B,h,w,>=3] f32 (channel-contiguous) -> depth [B,h*k,w*k] f32 (already / max_depth)."""
+    _lib.require_gpu(raw)
+    B, h, w, _ = raw.shape
+    assert raw.dtype == torch.float32
+    depth = torch.empty((B, h * k, w * k), dtype=torch.float32, device=raw.device)
+    plane = torch.empty((B, h, w, 4), dtype=torch.float32, device=raw.device) if want_plane else None
+    call("bts_lpg_head_fwd", _p(raw), pix_stride(raw), _p(depth), _p(plane), B, h, w, k, float(max_depth), stream_ptr())
+    return (depth, plane) if want_plane else depth
+
+
+def lpg_head_bwd(raw, grad_depth, k, max_depth, grad_dtype, grad_pad):
+    B, h, w, _ = raw.shape
+    g = torch.empty((B, h, w, grad_pad), dtype=grad_dtype, device=raw.device)
+    call("bts_lpg_head_bwd", _p(raw), pix_stride(raw), _p(grad_depth), _p(g), dtype_code(grad_dtype), grad_pad, grad_pad,
+         B, h, w, k, float(max_depth), stream_ptr())
+    return g
+
+
+def pack_maps(maps, ds, N, H, W, dtype):
+    """maps: list (<=4) of f32 [N, H*ds, W*ds] tensors -> NHWC [N,H,W,VEC] slot buffer."""
+    Cp = vec_of(dtype)
+    dst = torch.empty((N, H, W, Cp), dtype=dtype, device=maps[0].device)
+    n = len(maps)
+    src = (C.c_void_p * n)(*[m.data_ptr() for m in maps])
+    dsa = (C.c_int * n)(*ds)
+    call("bts_pack_maps", src, dsa, n, _p(dst), dtype_code(dtype), Cp, Cp, N, H, W, stream_ptr())
+    return dst
+
+
+def unpack_maps(gdst, gmaps, ds):
+    """Adjoint of pack_maps: accumulates channel s of gdst into gmaps[s] (f32, strided by ds[s])."""
+    N, H, W, _ = gdst.shape
+    n = len(gmaps)
+    dst = (C.c_void_p * n)(*[m.data_ptr() for m in gmaps])
+    dsa = (C.c_int * n)(*ds)
+    call("bts_unpack_maps", _p(gdst), dtype_code(gdst.dtype), pix_stride(gdst), dst, dsa, n, N, H, W, stream_ptr())
+
+
+# ---------------------------------------------------------------------------------------------
+# silog
+# ---------------------------------------------------------------------------------------------
+def silog_fwd(est, gt, mask, variance_focus, gt_threshold=0.0):
+    _lib.require_gpu(est)
+    n = est.numel()
+    ws = torch.empty(call("bts_silog_workspace_bytes", n) // 8, dtype=torch.float64, device=est.device)
+    stats = torch.empty(3, dtype=torch.float64, device=est.device)
+    loss = torch.empty(1, dtype=torch.float32, device=est.device)
+    call("bts_silog_fwd", _p(est), _p(gt), _p(mask), float(gt_threshold), n, float(variance_focus), _p(ws), _p(stats),
+         _p(loss), stream_ptr())
+    return loss, stats
+
+
+def silog_bwd(est, gt, mask, variance_focus, stats, loss, grad_loss, gt_threshold=0.0):
+    g = torch.empty_like(est)
+    call("bts_silog_bwd", _p(est), _p(gt), _p(mask), float(gt_threshold), est.numel(), float(variance_focus), _p(stats),
+         _p(loss), _p(grad_loss), _p(g), stream_ptr())
+    return g
+
+
+# ---------------------------------------------------------------------------------------------
+# layout / elementwise / BN
+# ---------------------------------------------------------------------------------------------
+def nchw_to_nhwc(src, dtype, relu=False, c_pad=None):
+    """src f32 [N,C,H,W] contiguous -> NHWC [N,H,W,c_pad or C] in `dtype` (pad channels zero)."""
+    _lib.require_gpu(src)
+    N, Cc, H, W = src.shape
+    Cp = c_pad or Cc
+    dst = (torch.zeros if Cp != Cc else torch.empty)((N, H, W, Cp), dtype=dtype, device=src.device)
+    call("bts_nchw_to_nhwc", _p(src), _p(dst), dtype_code(dtype), Cp, N, Cc, H, W, int(relu), stream_ptr())
+    return dst
+
+
+def nhwc_to_nchw(src, Cc, relu_src=None):
+    N, H, W, _ = src.shape
+    dst = torch.empty((N, Cc, H, W), dtype=torch.float32, device=src.device)
+    call("bts_nhwc_to_nchw", _p(src), dtype_code(src.dtype), pix_stride(src), _p(dst), _p(relu_src), N, Cc, H, W, stream_ptr())
+    return dst
+
+
+def bn_stats(x):
+    M, Cc = npix(x), x.shape[3]
+    ws = torch.empty(call("bts_bn_stats_workspace_bytes", M, Cc) // 4, dtype=torch.float32, device=x.device)
+    mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    var = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    call("bts_bn_stats", _p(x), dtype_code(x.dtype), pix_stride(x), M, Cc, _p(ws), _p(mean), _p(var), stream_ptr())
+    return mean, var
+
+
+def bn_prepare(mean, var, M, gamma, beta, eps, momentum=0.0, running_mean=None, running_var=None):
+    Cc = mean.numel()
+    invstd = torch.empty_like(mean)
+    scale = torch.empty_like(mean)
+    shift = torch.empty_like(mean)
+    call("bts_bn_prepare", _p(mean), _p(var), Cc, M, _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
+         _p(running_var), _p(invstd), _p(scale), _p(shift), stream_ptr())
+    return invstd, scale, shift
+
+
+def affine_act(x, scale, shift, act, out=None):
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    call("bts_affine_act", _p(x), dtype_code(x.dtype), pix_stride(x), _p(out), dtype_code(out.dtype), pix_stride(out),
+         npix(x), x.shape[3], _p(scale), _p(shift), act, stream_ptr())
+    return out
+
+
+def bn_bwd(dy, x, mean, invstd, gamma, beta, relu, dx, accumulate, use_batch_stats=True):
+    """Returns (dbeta, dgamma) sums and writes / accumulates dx."""
+    M, Cc = npix(x), x.shape[3]
+    sums = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    ws = torch.empty(call("bts_bn_stats_workspace_bytes", M, Cc) // 4, dtype=torch.float32, device=x.device)
+    call("bts_bn_bwd_reduce", _p(dy), pix_stride(dy), _p(x), pix_stride(x), dtype_code(x.dtype), M, Cc, _p(mean), _p(invstd),
+         _p(gamma), _p(beta), int(relu), _p(ws), _p(sums), stream_ptr())
+    call("bts_bn_bwd_apply", _p(dy), pix_stride(dy), _p(x), pix_stride(x), _p(dx), pix_stride(dx), dtype_code(x.dtype), M, Cc,
+         _p(mean), _p(invstd), _p(gamma), _p(beta), int(relu), _p(sums), int(use_batch_stats), int(accumulate), stream_ptr())
+    return sums[0], sums[1]
+
+
+def act_bwd(dy, y, act, out=None, out_dtype=None, out_channels=None, y_scale=1.0, y_scale_n=None):
+    """dz = dy * act'(y).  dy/y may be NHWC [N,H,W,C] or single-channel maps [N,H,W]."""
+    if dy.dim() == 3:
+        N, H, W = dy.shape
+        Cc, dys, ys, M = 1, 1, 1, N * H * W
+        if out is None:
+            oc = out_channels or 1
+            out = torch.zeros((N, H, W, oc), dtype=out_dtype or dy.dtype, device=dy.device)
+    else:
+        Cc, dys, ys, M = dy.shape[3], pix_stride(dy), pix_stride(y), npix(dy)
+        if out is None:
+            out = torch.empty(dy.shape, dtype=out_dtype or dy.dtype, device=dy.device)
+    ppi = M // dy.shape[0]
+    call("bts_act_bwd", _p(dy), dtype_code(dy.dtype), dys, _p(y), dtype_code(y.dtype), ys, _p(out), dtype_code(out.dtype),
+         pix_stride(out), M, Cc, act, float(y_scale), _p(y_scale_n), ppi, stream_ptr())
+    return out
+
+
+def add_to(x, y, accumulate=True):
+    call("bts_add_to", _p(x), dtype_code(x.dtype), pix_stride(x), _p(y), dtype_code(y.dtype), pix_stride(y), npix(x), x.shape[3],
+         int(accumulate), stream_ptr())
+    return y

@@ -1,0 +1,234 @@
+/* libbts_amd.so -- C ABI of the MI355X (gfx950) BTS decoder / LPG / silog hot path.
+ *
+ * Boundary contract (models the reference's only native operator interface, the
+ * TensorFlow custom-op functors in tensorflow/custom_layer/local_planar_guidance.h:22-49
+ * and their wrappers local_planar_guidance.cc:182-231, 365-416):
+ *   - plain C, raw device pointers + sizes; no framework types;
+ *   - the CALLER allocates every output and every workspace; the library never
+ *     allocates, frees, synchronises or keeps mutable global state;
+ *   - every entry point enqueues on the caller's stream (`stream` is a hipStream_t
+ *     passed as void*; the reference enqueues on d.stream() then blocks with
+ *     d.synchronize(), local_planar_guidance.cu:88-91 -- we do not block);
+ *   - return value: 0 on success, a negative BTS_ERR_* code otherwise (the
+ *     reference functors return void and validate in the wrapper with
+ *     OP_REQUIRES/DCHECK, local_planar_guidance.cc:190-205; here validation is in
+ *     the callee so any FFI binding gets it);
+ *   - re-entrant: may be called concurrently from several host threads (PyTorch's
+ *     main thread and its autograd thread).
+ *
+ * Activation layout inside the decoder is NHWC ("pixel-major": [N][H][W][C], C
+ * contiguous) in f32 or bf16; a tensor argument is always (pointer, pixel stride in
+ * ELEMENTS) so channel slices of wider buffers can be passed without copies.
+ * Parameters and all statistics / gradients of parameters are f32.
+ */
+#ifndef BTS_AMD_H_
+#define BTS_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BTS_AMD_ABI_VERSION 1
+
+enum { BTS_F32 = 0, BTS_BF16 = 1 };
+enum { BTS_ACT_NONE = 0, BTS_ACT_ELU = 1, BTS_ACT_SIGMOID = 2, BTS_ACT_RELU = 3 };
+enum {
+    BTS_OK = 0,
+    BTS_ERR_ARG = -1,      /* invalid argument (null pointer, bad size, bad alignment, bad enum) */
+    BTS_ERR_LAUNCH = -2,   /* hipLaunch failed (hipGetLastError != hipSuccess) */
+    BTS_ERR_UNSUPPORTED = -3
+};
+
+typedef void* bts_stream_t; /* hipStream_t */
+
+int bts_abi_version(void);
+/* Number of the HIP device the calling thread is bound to, or <0: sanity check that the
+ * library shares the caller's HIP runtime. */
+int bts_current_device(void);
+
+/* ------------------------------------------------------------------------------------
+ * Local planar guidance -- the reference's native op.
+ * Replaces LocalPlanarGuidanceKernel<GPUDevice>::operator() (local_planar_guidance.h:22-34,
+ * .cu:76-92) and pytorch/bts.py:124-146.  plane_eq is [B][h][w][4] (the TF op's NHWC
+ * layout, .cu:59-66); depth is [B][h*k][w*k]:
+ *     depth = (n4 / (n1*u + n2*v + n3)) / depth_div,
+ * u = ((col mod k) - (k-1)/2)/k, v likewise from the row, each product/sum rounded separately
+ * (no FMA contraction) so the result is bit-identical to the reference's op order.
+ * `focal` is accepted for signature parity and ignored, exactly as the reference does
+ * (.cu:56, bts.py:132).  depth_div = 1 reproduces the op; max_depth fuses bts.py:228.
+ * ---------------------------------------------------------------------------------- */
+int bts_lpg_fwd(const float* plane_eq, const float* focal, float* depth,
+                int batch, int in_h, int in_w, int upratio, float depth_div, bts_stream_t stream);
+
+/* Gradient w.r.t. plane_eq.  Replaces LocalPlanarGuidanceGradKernel (local_planar_guidance.h:36-49,
+ * .cu:154-171) but computes the TRUE derivative (what PyTorch autograd yields for bts.py:146);
+ * the reference CUDA gradient omits the factor n4 in d/dn1..n3 (.cu:143-145) and is not the
+ * parity target.  grad_plane_eq is [B][h][w][4], overwritten. */
+int bts_lpg_bwd(const float* grad_depth, const float* plane_eq, const float* focal, float* grad_plane_eq,
+                int batch, int in_h, int in_w, int upratio, float depth_div, bts_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused LPG head: raw plane parameters -> sigmoid/angles (bts.py:112-120) -> L2-normalise
+ * (bts.py:223-226) -> LPG (bts.py:124-146) -> /max_depth (bts.py:228) in one pass, one thread
+ * per coarse cell (transcendentals once per cell, k*k divisions, coalesced row stores).
+ *   raw       f32, cell (b,i,j) at raw[((b*h+i)*w+j)*raw_stride + 0..2]  (last 1x1 conv, no activation)
+ *   depth     [B][h*k][w*k] f32  (the model output lpgKxK / max_depth)
+ *   plane_eq  [B][h][w][4] f32   normalised plane (nullable; diagnostic / TF-op-boundary tests)
+ * Backward recomputes the plane from raw (nothing but raw is saved):
+ *   grad_depth [B][H][W] f32 -> grad_raw: 3 channels at grad_stride in grad_dtype, plus
+ *   (grad_pad - 3) zero channels so the buffer can feed bts_conv_wgrad / data-grad directly.
+ * ---------------------------------------------------------------------------------- */
+int bts_lpg_head_fwd(const float* raw, int raw_stride, float* depth, float* plane_eq,
+                     int batch, int in_h, int in_w, int upratio, float max_depth, bts_stream_t stream);
+int bts_lpg_head_bwd(const float* raw, int raw_stride, const float* grad_depth,
+                     void* grad_raw, int grad_dtype, int grad_stride, int grad_pad,
+                     int batch, int in_h, int in_w, int upratio, float max_depth, bts_stream_t stream);
+
+/* Gather up to 4 single-channel f32 maps into channels 0..n-1 of an NHWC buffer (the depth-map
+ * slots of the concat inputs of conv3 / conv2 / conv1, bts.py:233, 247, 260): dst pixel (n,y,x)
+ * channel s = src[s][n][y*ds[s]][x*ds[s]] where src[s] is [N][H*ds[s]][W*ds[s]]
+ * (ds = 4 / 2 implements the nearest down-sample of bts.py:229 / 243).  Channels n..C-1 are zeroed.
+ * bts_unpack_maps is its adjoint: gsrc[s][n][y*ds][x*ds] += gdst[n][y][x][s]. */
+int bts_pack_maps(const float* const* src, const int* ds, int n_src, void* dst, int dst_dtype, int dst_stride,
+                  int C, int N, int H, int W, bts_stream_t stream);
+int bts_unpack_maps(const void* gdst, int dst_dtype, int dst_stride, float* const* gsrc, const int* ds, int n_src,
+                    int N, int H, int W, bts_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * silog loss (pytorch/bts.py:41-48): loss = 10*sqrt(mean(d^2) - vf*mean(d)^2),
+ * d = log(est) - log(gt) over pixels with gt > gt_threshold (the mask built at
+ * bts_main.py:449-452; a caller-supplied byte mask may be given instead).
+ *   workspace: >= bts_silog_workspace_bytes(n) bytes, 8-byte aligned
+ *   stats_out: double[3] = {sum d, sum d^2, count} (kept for backward)
+ *   loss_out : float[1]
+ * ---------------------------------------------------------------------------------- */
+long bts_silog_workspace_bytes(long n);
+int bts_silog_fwd(const float* est, const float* gt, const uint8_t* mask /*nullable*/, float gt_threshold,
+                  long n, float variance_focus, void* workspace, double* stats_out, float* loss_out,
+                  bts_stream_t stream);
+int bts_silog_bwd(const float* est, const float* gt, const uint8_t* mask, float gt_threshold, long n,
+                  float variance_focus, const double* stats, const float* loss, const float* grad_loss,
+                  float* grad_est, bts_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on MFMA (f32: v_mfma_f32_32x32x2_f32, bf16: v_mfma_f32_32x32x16_bf16).
+ * One descriptor covers every contraction of the decoder:
+ *   3x3 / dilated 3x3 / 1x1 convs over a concatenation of up to BTS_MAX_SEG input tensors
+ *   (torch.cat eliminated), nearest-x2-upsample + 3x3 ("upconv", bts.py:69-80) as four 2x2
+ *   sub-pixel phase convolutions on the low-resolution input, and the data-gradient of both.
+ * Conv domain: grid [N][Hg][Wg]; for tap t of phase p the input pixel is
+ *   ((y + dy[pT+t])*isc + ioy[pT+t], (x + dx[pT+t])*isc + iox[pT+t]), zero when
+ *   (y+dy, x+dx) falls outside the grid; the output pixel is (y*osc + (p>>1), x*osc + (p&1)).
+ * Weights are pre-packed [Cout][nphase*T][Ktot] (Ktot = sum of segment channels, K contiguous)
+ * in the activation dtype (see bts_pack_weight).
+ * ---------------------------------------------------------------------------------- */
+#define BTS_MAX_SEG 6
+#define BTS_MAX_TAP 16
+
+typedef struct {
+    const void* ptr; /* first channel of pixel (0,0,0) */
+    int32_t C;       /* channels, multiple of 16/sizeof(elem) */
+    int32_t stride;  /* elements between consecutive pixels */
+} bts_seg_t;
+
+typedef struct {
+    int32_t dtype;          /* BTS_F32 / BTS_BF16: input + packed-weight dtype */
+    int32_t N, Hg, Wg;      /* conv-domain grid */
+    int32_t nseg;
+    bts_seg_t seg[BTS_MAX_SEG];
+    int32_t Hx, Wx;         /* spatial size of the input tensors */
+    int32_t isc;            /* input coordinate scale (1, or 2 for the upconv data-gradient) */
+    int32_t nphase;         /* 1 or 4 */
+    int32_t T;              /* taps per phase; nphase*T <= BTS_MAX_TAP */
+    int16_t dy[BTS_MAX_TAP], dx[BTS_MAX_TAP], ioy[BTS_MAX_TAP], iox[BTS_MAX_TAP];
+    const void* w;          /* packed weights */
+    int32_t Cout;
+    void* y;                /* output, NHWC */
+    int32_t y_dtype;        /* BTS_F32 / BTS_BF16 */
+    int32_t y_stride;
+    int32_t Hy, Wy;         /* spatial size of the output tensor */
+    int32_t osc;            /* output coordinate scale (1, or 2 for upconv forward) */
+    int32_t act;            /* BTS_ACT_* applied to the accumulator */
+    float out_scale;        /* multiplies act(acc) */
+    const float* out_scale_n; /* optional [N] per-image multiplier (kitti focal scaling, bts.py:263-264) */
+    int32_t accumulate;     /* 1: y += result (gradient accumulation); requires act == NONE */
+} bts_conv_desc_t;
+
+int bts_conv_fwd(const bts_conv_desc_t* d, bts_stream_t stream);
+
+/* Weight gradient of the convolution described by `d` (d->w, d->y unused):
+ *   dw[co][p*T+t][k] += sum_pixels dz[out pixel][co] * x_t[in pixel][k]
+ * dz has the geometry of d's output (stride dz_stride, dtype d->dtype).  dw is f32,
+ * [Cout][nphase*T][Ktot], accumulated with atomics: the caller zeroes it. */
+int bts_conv_wgrad(const bts_conv_desc_t* d, const void* dz, int dz_stride, float* dw, bts_stream_t stream);
+
+/* Pack a PyTorch-layout f32 weight [Cout][Cin][KK] (KK = kh*kw = 1 or 9) for bts_conv_fwd.
+ *   mode 0 (forward):   out[r][t][k] = sum_{s in tapmask[t]} w[r][cmap[k]][s],      r < R = Cout
+ *   mode 1 (data-grad): out[r][t][k] = sum_{s in tapmask[t]} w[k][cmap[r]][s],      k < Cout, zero for K > k >= Cout
+ * cmap (device, int32) maps a padded channel index to the original input channel or -1 (zero).
+ * tapmask (host, T entries): bit s set = source tap s contributes (one bit for plain convs;
+ * several for the pre-summed sub-pixel phases of upconv).  out dtype = `dtype`. */
+int bts_pack_weight(const float* w, int Cout, int Cin, int KK, int mode, const int32_t* cmap,
+                    int R, int K, int T, const uint16_t* tapmask, int dtype, void* out, bts_stream_t stream);
+
+/* Inverse of mode 0 for gradients: gw[co][ci][s] (+)= sum_{t: s in tapmask[t]} dwp[co][t][kinv[ci]],
+ * kinv (device int32 [Cin]) maps an original input channel to its padded index. */
+int bts_unpack_wgrad(const float* dwp, int Cout, int Cin, int KK, const int32_t* kinv, int K, int T,
+                     const uint16_t* tapmask, float* gw, int accumulate, bts_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Elementwise / normalisation kernels (HBM-bound)
+ * ---------------------------------------------------------------------------------- */
+/* NCHW f32 -> NHWC (dtype), optional ReLU (bts.py:198): dst[n][h][w][c] at dst_stride. */
+int bts_nchw_to_nhwc(const float* src, void* dst, int dst_dtype, int dst_stride, int N, int C, int H, int W,
+                     int relu, bts_stream_t stream);
+/* NHWC (dtype) gradient -> NCHW f32; if relu_src != NULL (the NCHW forward input) multiplies by (src > 0). */
+int bts_nhwc_to_nchw(const void* src, int src_dtype, int src_stride, float* dst, const float* relu_src,
+                     int N, int C, int H, int W, bts_stream_t stream);
+
+/* Per-channel batch statistics of an NHWC tensor over M = N*H*W pixels (train-mode BatchNorm,
+ * bts.py:154 etc.): mean[c], var[c] (biased).  workspace >= bts_bn_stats_workspace_bytes(M, C). */
+long bts_bn_stats_workspace_bytes(long M, int C);
+int bts_bn_stats(const void* x, int dtype, int stride, long M, int C, void* workspace,
+                 float* mean, float* var, bts_stream_t stream);
+/* From (mean, var): invstd = 1/sqrt(var+eps), scale = gamma*invstd, shift = beta - mean*scale, and --
+ * when running_mean/var are given -- the nn.BatchNorm2d running-stat update with `momentum` and the
+ * unbiased variance (M/(M-1)).  Eval mode: pass the running stats as mean/var and NULL running_*.
+ * invstd is nullable. */
+int bts_bn_prepare(const float* mean, const float* var, int C, long M, const float* gamma, const float* beta,
+                   float eps, float momentum, float* running_mean, float* running_var, float* invstd,
+                   float* scale, float* shift, bts_stream_t stream);
+/* y = act(x * scale[c] + shift[c]), act in {NONE, RELU}; scale/shift f32 [C]. */
+int bts_affine_act(const void* x, int x_dtype, int x_stride, void* y, int y_dtype, int y_stride,
+                   long M, int C, const float* scale, const float* shift, int act, bts_stream_t stream);
+/* BatchNorm(+ReLU) backward, two passes.
+ * pass 1: sums[0][c] = sum dy', sums[1][c] = sum dy' * xhat, with dy' = dy * (relu ? (xhat*gamma+beta > 0) : 1),
+ *         xhat = (x - mean) * invstd.   workspace as bts_bn_stats.
+ * pass 2: dx (+)= gamma*invstd * (dy' - (use_batch_stats ? sums0/M + xhat*sums1/M : 0)). */
+int bts_bn_bwd_reduce(const void* dy, int dy_stride, const void* x, int x_stride, int dtype, long M, int C,
+                      const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
+                      void* workspace, float* sums /*[2][C]*/, bts_stream_t stream);
+int bts_bn_bwd_apply(const void* dy, int dy_stride, const void* x, int x_stride, void* dx, int dx_stride,
+                     int dtype, long M, int C, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, int relu, const float* sums, int use_batch_stats, int accumulate,
+                     bts_stream_t stream);
+/* dz = dy * act'(y) given the activation OUTPUT y (ELU: y>0 ? 1 : y+1; SIGMOID: y(1-y); RELU: y>0). */
+int bts_act_bwd(const void* dy, int dy_dtype, int dy_stride, const void* y, int y_dtype, int y_stride,
+                void* dz, int dz_dtype, int dz_stride, long M, int C, int act, float y_scale,
+                const float* y_scale_n, long pix_per_image, bts_stream_t stream);
+/* y (+)= x for NHWC slices (gradient accumulation between differently-strided buffers). */
+int bts_add_to(const void* x, int x_dtype, int x_stride, void* y, int y_dtype, int y_stride, long M, int C,
+               int accumulate, bts_stream_t stream);
+
+/* Fused multi-tensor AdamW step (torch.optim.AdamW semantics, bts_main.py:371-373, 456-460) over a
+ * flat list of f32 tensors: ptr arrays live on the DEVICE. */
+int bts_adamw_step(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                   const long* sizes, int n_tensors, long max_size, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, float bias_c1, float bias_c2, bts_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BTS_AMD_H_ */

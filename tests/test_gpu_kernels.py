@@ -1,0 +1,257 @@
+"""GPU parity tests, kernel level: every HIP kernel family against the CPU oracle / plain PyTorch
+f32 CPU math on the same seeded inputs, through the C ABI (bts_amd.ops / bts_amd.conv).
+
+Tolerances: f32 paths 1e-4 relative (north_star); the LPG op itself is expected bit-exact for
+integer-valued offsets (checked to 1e-6 and reported); bf16 paths 2e-2 relative (bf16 has 8
+mantissa bits; stated here, not a parity claim).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import bts_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def load(golden_dir, name):
+    return np.load("%s/%s.npz" % (golden_dir, name))
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [8, 4, 2])
+def test_lpg_op_golden(golden_dir, k):
+    """local_planar_guidance fwd/bwd vs the reference's own outputs (tests/golden/lpg.npz)."""
+    from bts_amd.model import local_planar_guidance
+    g = load(golden_dir, "lpg")
+    eq = torch.tensor(g["k%d_eq" % k], device=DEV, requires_grad=True)
+    out = local_planar_guidance(k)(eq, torch.ones(eq.shape[0], device=DEV))
+    ref = torch.tensor(g["k%d_out" % k])
+    assert out.shape == ref.shape
+    exact = (out.cpu() == ref).float().mean().item()
+    print("lpg k=%d bit-exact fraction %.4f rel %.3e" % (k, exact, rel(out, ref)))
+    assert rel(out, ref) < 1e-6
+    out.backward(torch.tensor(g["k%d_gout" % k], device=DEV))
+    assert rel(eq.grad, torch.tensor(g["k%d_geq" % k])) < 1e-4
+
+
+@pytest.mark.parametrize("k", [8, 4, 2])
+def test_lpg_head_vs_oracle(k):
+    from bts_amd import ops
+    gen = torch.Generator().manual_seed(100 + k)
+    B, h, w = 2, 7, 9
+    raw = torch.randn(B, h, w, 4, generator=gen)
+    raw_c = raw.permute(0, 3, 1, 2)[:, :3].clone().requires_grad_(True)
+    eq = O.normalize_plane(O.plane_from_raw(raw_c, 80.0))
+    ref = O.lpg(eq, k) / 80.0
+    depth, plane = ops.lpg_head_fwd(raw.to(DEV), k, 80.0, want_plane=True)
+    assert rel(depth, ref) < 1e-4
+    assert rel(plane, eq.permute(0, 2, 3, 1)) < 1e-5
+    gy = torch.randn(ref.shape, generator=gen)
+    ref.backward(gy)
+    for dt, tol in ((torch.float32, 1e-4), (torch.bfloat16, 2e-2)):
+        pad = 4 if dt == torch.float32 else 8
+        graw = ops.lpg_head_bwd(raw.to(DEV), gy.to(DEV), k, 80.0, dt, pad)
+        assert rel(graw[..., :3].float(), raw_c.grad.permute(0, 2, 3, 1)) < tol
+        assert graw[..., 3:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("tag", ["kitti", "nyu"])
+def test_silog_golden(golden_dir, tag):
+    from bts_amd.model import silog_loss
+    g = load(golden_dir, "silog")
+    est = torch.tensor(g[tag + "_est"], device=DEV, requires_grad=True)
+    gt = torch.tensor(g[tag + "_gt"], device=DEV)
+    mask = gt > (1.0 if tag == "kitti" else 0.1)
+    loss = silog_loss(float(g[tag + "_vf"]))(est, gt, mask)
+    assert loss.dim() == 0
+    assert abs(loss.item() - float(g[tag + "_loss"])) / float(g[tag + "_loss"]) < 1e-5
+    loss.backward()
+    assert rel(est.grad, torch.tensor(g[tag + "_gest"])) < 1e-4
+
+
+def test_silog_ragged_and_empty_mask():
+    """n not a multiple of 4, and a mask selecting a single pixel (edge cases of the reduction)."""
+    from bts_amd.model import silog_loss
+    gen = torch.Generator().manual_seed(5)
+    est = torch.rand(1, 1, 7, 9, generator=gen) * 5 + 0.5
+    gt = torch.rand(1, 1, 7, 9, generator=gen) * 5 + 0.5
+    mask = torch.rand(1, 1, 7, 9, generator=gen) > 0.5
+    ref = O.silog(est, gt, mask, 0.85)
+    got = silog_loss(0.85)(est.to(DEV), gt.to(DEV), mask.to(DEV))
+    assert abs(got.item() - ref.item()) / ref.item() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+def _nhwc(x, dt, v):
+    """NCHW f32 cpu -> NHWC device tensor with channels zero-padded to a multiple of v."""
+    N, C, H, W = x.shape
+    cp = (C + v - 1) // v * v
+    t = torch.zeros(N, H, W, cp, dtype=dt, device=DEV)
+    t[..., :C] = x.permute(0, 2, 3, 1).to(DEV).to(dt)
+    return t
+
+
+CONV_CASES = [
+    # name, cout, seg_channels, kk, dil, up, (N,H,W)
+    ("c3x3_2seg", 40, [16, 24], 9, 1, False, (2, 9, 13)),
+    ("c3x3_slot", 16, [8, 8, 1], 9, 1, False, (2, 8, 12)),
+    ("c3x3_big", 136, [64, 40], 9, 1, False, (1, 12, 20)),
+    ("dil6", 24, [32], 9, 6, False, (2, 10, 14)),
+    ("dil24", 16, [16], 9, 24, False, (1, 13, 17)),
+    ("c1x1_wide", 64, [72], 1, 1, False, (2, 6, 10)),
+    ("c1x1_to3", 3, [8], 1, 1, False, (2, 5, 7)),
+    ("c3x3_to1", 1, [16], 9, 1, False, (2, 8, 8)),
+    ("up_small", 16, [24], 9, 1, True, (2, 5, 6)),
+    ("up_big", 72, [136], 9, 1, True, (1, 6, 9)),
+    ("daspp6seg", 32, [16, 8, 8, 8, 8, 8], 9, 1, False, (1, 9, 11)),
+]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(case, dt):
+    """Implicit-GEMM conv (forward, data-gradient, weight-gradient) vs F.conv2d autograd on CPU f32."""
+    from bts_amd.conv import ConvLayer
+    from bts_amd import ops
+    from bts_amd._lib import ACT_NONE
+    name, cout, segc, kk, dil, up, (N, H, W) = case
+    v = 4 if dt == torch.float32 else 8
+    tol = 1e-4 if dt == torch.float32 else 2e-2
+    gen = torch.Generator().manual_seed(sum(map(ord, name)))
+    cin = sum(segc)
+    xs = [torch.randn(N, c, H, W, generator=gen) for c in segc]
+    k = 3 if kk == 9 else 1
+    w = torch.randn(cout, cin, k, k, generator=gen) * (1.0 / (cin * kk) ** 0.5)
+    if dt == torch.bfloat16:   # compare against the same bf16-rounded operands
+        xs = [x.to(dt).float() for x in xs]
+    xs_r = [x.clone().requires_grad_(True) for x in xs]
+    w_r = w.clone().requires_grad_(True)
+    xin = torch.cat(xs_r, 1)
+    if up:
+        xin = xin.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    wq = w_r.to(dt).float() if dt == torch.bfloat16 else w_r
+    ref = F.conv2d(xin, wq, padding=dil if kk == 9 else 0, dilation=dil)
+    gy = torch.randn(ref.shape, generator=gen)
+    if dt == torch.bfloat16:
+        gy = gy.to(dt).float()
+    ref.backward(gy)
+
+    L = ConvLayer(name, cout, segc, kk, dil, up)
+    wd_dev = w.to(DEV)
+    segs = [_nhwc(x, dt, v) for x in xs]
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    cp = (cout + v - 1) // v * v
+    out = torch.zeros(N, Ho, Wo, cp, dtype=dt, device=DEV)
+    L.forward(segs, L.pack_fwd(wd_dev, dt), out, ACT_NONE)
+    torch.cuda.synchronize()
+    e = rel(out[..., :cout].float().permute(0, 3, 1, 2), ref)
+    print("%s %s fwd rel %.3e" % (name, dt, e))
+    assert e < tol, "fwd"
+    assert out[..., cout:].abs().max().item() == 0.0 if cp > cout else True
+
+    dz = _nhwc(gy, dt, v)
+    for i, (x, c) in enumerate(zip(xs_r, segc)):
+        gx = torch.empty_like(segs[i])
+        L.dgrad(dz, L.pack_dgrad(wd_dev, dt, i), i, gx, False)
+        e = rel(gx[..., :c].float().permute(0, 3, 1, 2), x.grad)
+        print("%s %s dgrad seg%d rel %.3e" % (name, dt, i, e))
+        assert e < tol, "dgrad seg %d" % i
+        # accumulate mode adds on top
+        L.dgrad(dz, L.pack_dgrad(wd_dev, dt, i), i, gx, True)
+        assert rel(gx[..., :c].float().permute(0, 3, 1, 2), 2 * x.grad) < 2 * tol
+    gw = L.wgrad(segs, dz)
+    e = rel(gw, w_r.grad)
+    print("%s %s wgrad rel %.3e" % (name, dt, e))
+    assert e < (1e-4 if dt == torch.float32 else 3e-2), "wgrad"
+
+
+def test_conv_epilogues():
+    """ELU / sigmoid*scale_n epilogues and the single-channel f32 map output."""
+    from bts_amd.conv import ConvLayer
+    from bts_amd._lib import ACT_ELU, ACT_SIGMOID
+    gen = torch.Generator().manual_seed(3)
+    N, H, W = 2, 8, 12
+    x = torch.randn(N, 16, H, W, generator=gen)
+    w = torch.randn(24, 16, 3, 3, generator=gen) * 0.1
+    L = ConvLayer("e", 24, [16], 9)
+    seg = [_nhwc(x, torch.float32, 4)]
+    out = torch.empty(N, H, W, 24, device=DEV)
+    L.forward(seg, L.pack_fwd(w.to(DEV), torch.float32), out, ACT_ELU)
+    assert rel(out.permute(0, 3, 1, 2), F.elu(F.conv2d(x, w, padding=1))) < 1e-4
+    w1 = torch.randn(1, 16, 3, 3, generator=gen) * 0.1
+    L1 = ConvLayer("g", 1, [16], 9)
+    sc = torch.tensor([1.01, 0.99], device=DEV)
+    m = torch.empty(N, H, W, device=DEV)
+    L1.forward(seg, L1.pack_fwd(w1.to(DEV), torch.float32), m, ACT_SIGMOID, 80.0, sc)
+    ref = 80.0 * torch.sigmoid(F.conv2d(x, w1, padding=1)) * sc.cpu().view(-1, 1, 1, 1)
+    assert rel(m.unsqueeze(1), ref) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("relu", [False, True])
+def test_batchnorm_train_fwd_bwd(dt, relu):
+    """bn_stats + bn_prepare + affine_act and the two-pass backward vs F.batch_norm autograd (CPU f32)."""
+    from bts_amd import ops
+    from bts_amd._lib import ACT_NONE, ACT_RELU
+    gen = torch.Generator().manual_seed(7)
+    N, C, H, W = 3, 40, 9, 11
+    v = 4 if dt == torch.float32 else 8
+    tol = 1e-4 if dt == torch.float32 else 2e-2
+    x = torch.randn(N, C, H, W, generator=gen) * 1.5 + 0.3
+    if dt == torch.bfloat16:
+        x = x.to(dt).float()
+    g = torch.rand(C, generator=gen) + 0.5
+    b = torch.rand(C, generator=gen) - 0.5
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.batch_norm(xr, rm, rv, gr, br, True, 0.01, 1.1e-5)
+    if relu:
+        y = F.relu(y)
+    gy = torch.randn(y.shape, generator=gen)
+    y.backward(gy)
+
+    xt = _nhwc(x, dt, v)
+    mean, var = ops.bn_stats(xt)
+    rm_d, rv_d = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    invstd, scale, shift = ops.bn_prepare(mean, var, N * H * W, g.to(DEV), b.to(DEV), 1.1e-5, 0.01, rm_d, rv_d)
+    yt = ops.affine_act(xt, scale, shift, ACT_RELU if relu else ACT_NONE)
+    assert rel(yt.float().permute(0, 3, 1, 2), y) < tol
+    assert rel(rm_d, rm) < 1e-4 and rel(rv_d, rv) < 1e-4
+    dx = torch.empty_like(xt)
+    db, dg = ops.bn_bwd(_nhwc(gy, dt, v), xt, mean, invstd, g.to(DEV), b.to(DEV), relu, dx, False)
+    assert rel(dx.float().permute(0, 3, 1, 2), xr.grad) < tol * 5
+    assert rel(dg, gr.grad) < tol * 5 and rel(db, br.grad) < tol * 5
+
+
+def test_layout_roundtrip_and_pack_maps():
+    from bts_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 24, 7, 10, generator=gen)
+    for dt, tol in ((torch.float32, 0.0), (torch.bfloat16, 8e-3)):
+        t = ops.nchw_to_nhwc(x.to(DEV), dt, relu=True)
+        assert rel(t.float().permute(0, 3, 1, 2), F.relu(x)) <= tol
+        back = ops.nhwc_to_nchw(t, 24, relu_src=x.to(DEV))
+        assert rel(back, F.relu(x)) <= tol
+    d8 = torch.randn(2, 16, 24, generator=gen).to(DEV)
+    slot = ops.pack_maps([d8], [4], 2, 4, 6, torch.float32)
+    assert torch.equal(slot[..., 0], d8[:, ::4, ::4]) and slot[..., 1:].abs().max().item() == 0
+    maps = [torch.randn(2, 8, 8, generator=gen).to(DEV) for _ in range(4)]
+    slot = ops.pack_maps(maps, [1, 1, 1, 1], 2, 8, 8, torch.bfloat16)
+    for s in range(4):
+        assert rel(slot[..., s].float(), maps[s]) < 8e-3
+    g = torch.randn(2, 8, 8, 8, generator=gen).to(DEV)
+    gm = [torch.zeros(2, 8, 8, device=DEV) for _ in range(4)]
+    ops.unpack_maps(g, gm, [1, 1, 1, 1])
+    for s in range(4):
+        assert torch.equal(gm[s], g[..., s])

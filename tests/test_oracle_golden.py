@@ -1,0 +1,111 @@
+"""Pin the CPU oracle (oracle/bts_oracle.py) against golden vectors produced by the UNMODIFIED
+reference (tools/make_golden.py, run in the build container) -- and, where /root/reference is
+present, against the live reference.  CPU only."""
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bts_oracle as O
+from oracle import ref_loader
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("k", [8, 4, 2])
+def test_lpg_matches_reference_golden(golden_dir, k):
+    g = np.load(golden_dir + "/lpg.npz")
+    eq = torch.tensor(g["k%d_eq" % k], requires_grad=True)
+    out = O.lpg(eq, k)
+    assert torch.equal(out, torch.tensor(g["k%d_out" % k]))          # bit-identical on CPU
+    out.backward(torch.tensor(g["k%d_gout" % k]))
+    assert rel(eq.grad, g["k%d_geq" % k]) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["r8_128", "r2_128", "r1_128", "r8_512", "r1_512"])
+def test_reduction_chain_matches_golden(golden_dir, tag):
+    g = np.load(golden_dir + "/reduction.npz")
+    final = tag.startswith("r1")
+    names = [k[len(tag) + 3:] for k in g.files if k.startswith(tag + "_w_")]
+    P = {"x." + n: torch.tensor(g[tag + "_w_" + n], requires_grad=True) for n in names}
+    x = torch.tensor(g[tag + "_x"], requires_grad=True)
+    y = O.reduction_chain(x, P, "x", 80.0, final)
+    assert rel(y, g[tag + "_y"]) < 1e-6
+    y.backward(torch.tensor(g[tag + "_gy"]))
+    assert rel(x.grad, g[tag + "_gx"]) < 1e-5
+    for n in names:
+        assert rel(P["x." + n].grad, g[tag + "_gw_" + n]) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["kitti", "nyu"])
+def test_silog_matches_golden(golden_dir, tag):
+    g = np.load(golden_dir + "/silog.npz")
+    est = torch.tensor(g[tag + "_est"], requires_grad=True)
+    gt = torch.tensor(g[tag + "_gt"])
+    loss = O.silog(est, gt, gt > (1.0 if tag == "kitti" else 0.1), float(g[tag + "_vf"]))
+    assert rel(loss, g[tag + "_loss"]) < 1e-6
+    loss.backward()
+    assert rel(est.grad, g[tag + "_gest"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag,train,ds", [("train_kitti", True, "kitti"), ("eval_nyu", False, "nyu")])
+def test_decoder_matches_golden(golden_dir, tag, train, ds):
+    g = np.load("%s/decoder_small_%s.npz" % (golden_dir, tag))
+    g0 = np.load("%s/decoder_small_train_kitti.npz" % golden_dir)
+    P = {k[2:]: torch.tensor(g0[k]) for k in g0.files if k.startswith("P/")}
+    for k, v in P.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    feats = [torch.tensor(g0["feat%d" % i], requires_grad=True) for i in range(5)]
+    md = 80.0 if ds == "kitti" else 10.0
+    outs, upd = O.decoder_forward(P, feats, torch.tensor(g["focal"]), md, ds, train)
+    for i, o in enumerate(outs):
+        assert rel(o, g["out%d" % i]) < 5e-6, i
+    gt = torch.tensor(g["gt"])
+    loss = O.silog(outs[4], gt, gt > (1.0 if ds == "kitti" else 0.1), 0.85)
+    assert rel(loss, g["loss"]) < 1e-5
+    (loss + sum((o * o).mean() for o in outs[:4])).backward()
+    worst = max(rel(P[k[2:]].grad, g[k]) for k in g.files if k.startswith("G/"))
+    assert worst < 2e-4, worst
+    for i, f in enumerate(feats):
+        assert rel(f.grad, g["gfeat%d" % i]) < 2e-4
+    for k, v in upd.items():
+        assert rel(v, g["B/" + k]) < 1e-5, k
+
+
+def test_param_factory_matches_reference_state_dict():
+    """Key names / order / shapes of the decoder state dict (110 tensors for DenseNet161)."""
+    specs = O.decoder_param_specs([96, 96, 192, 384, 2208], 512)
+    assert len(specs) == 110
+    if ref_loader.available():
+        ref = ref_loader.load_reference()
+        dec = ref.bts(NS(max_depth=80.0, dataset="kitti", encoder="densenet161_bts", bts_size=512),
+                      [96, 96, 192, 384, 2208], 512)
+        sd = dec.state_dict()
+        assert list(sd.keys()) == [k for k, _, _ in specs]
+        assert all(tuple(sd[k].shape) == tuple(s) for k, s, _ in specs)
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason="/root/reference not present (GPU box)")
+def test_oracle_vs_live_reference_c1_plumbing(golden_dir):
+    """configs[0]: BtsModel densenet121 416x544 batch-1 CPU forward of the reference reproduces the golden samples."""
+    ref = ref_loader.load_reference()
+    g = np.load(golden_dir + "/model_c1_densenet121.npz")
+    torch.manual_seed(int(g["model_seed"]))
+    model = ref.BtsModel(NS(encoder="densenet121_bts", max_depth=10.0, dataset="nyu", bts_size=512))
+    model.decoder.apply(ref.weights_init_xavier)
+    model.eval()
+    x = torch.randn(1, 3, 416, 544, generator=torch.Generator().manual_seed(int(g["input_seed"])))
+    with torch.no_grad():
+        outs = model(x, O.synth_focal(1, "nyu"))
+        feats = model.encoder(x)
+        P = model.decoder.state_dict()
+        outs_o, _ = O.decoder_forward(P, feats, O.synth_focal(1, "nyu"), 10.0, "nyu", False)
+    for i, (o, oo) in enumerate(zip(outs, outs_o)):
+        assert rel(o[:, :, ::8, ::8], g["out%d_s8" % i]) < 1e-4
+        assert rel(oo, o) < 1e-4
+    assert int(g["n_params"]) == sum(p.numel() for p in model.parameters())
