@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""Benchmark of the BTS train step (BASELINE.json metric: images/sec, DenseNet161-BTS 352x1216).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = forward (stock PyTorch-ROCm encoder under bf16 autocast + HIP decoder) + silog loss
++ backward + (N>1: RCCL gradient all-reduce overlapped with backward) + AdamW with the per-step
+poly LR of bts_main.py:456-460, on a synthetic batch already resident in HBM.  Weak scaling:
+8 images per GPU (BASELINE.json configs[2] = batch 64 over 8 GPUs, bts_main.py:351).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant HIP kernel family of the step (by summed device time, measured with HIP
+                  events on the launching stream inside the timed region): algorithmic FLOPs / time
+  cpu_baseline -- the CPU oracle (oracle/bts_oracle.py + the same stock encoder) timed on this
+                  host's cores on ONE image of the same shape (reported-only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace as NS
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--height", type=int, default=352)
+    ap.add_argument("--width", type=int, default=1216)
+    ap.add_argument("--encoder", default="densenet161_bts")
+    ap.add_argument("--dataset", default="kitti")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--channels-last", type=int, default=0)
+    return ap.parse_args()
+
+
+def set_misc(model):
+    """Freeze what bts_main.py:217-247 freezes by default ('Fixing first conv layer')."""
+    fixing = ["base_model.conv1", ".bn"] if "resne" in model.encoder.params.encoder else ["conv0", "norm"]
+    for name, p in model.encoder.named_parameters():
+        if any(x in name for x in fixing):
+            p.requires_grad = False
+
+
+def make_batch(args, dev, seed):
+    from oracle import bts_oracle as O     # synthetic-input recipe shared with the tests
+    gen = torch.Generator().manual_seed(seed)
+    B, H, W = args.batch, args.height, args.width
+    image = torch.randn(B, 3, H, W, generator=gen)
+    focal = O.synth_focal(B, args.dataset)
+    gt = O.synth_depth_gt(B, H, W, args.dataset, gen)
+    return image.to(dev), focal.to(dev), gt.to(dev)
+
+
+def cpu_baseline(args):
+    """Oracle train step (fwd + silog + bwd) on the host cores, one image of the bench shape, f32."""
+    import copy
+
+    from bts_amd.model import BtsModel
+    from oracle import bts_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    params = NS(encoder=args.encoder, max_depth=80.0 if args.dataset == "kitti" else 10.0, dataset=args.dataset, bts_size=512)
+    torch.manual_seed(0)
+    model = BtsModel(params)            # parameter container only: the oracle does the math
+    enc = model.encoder
+    P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+         for k, v in model.decoder.state_dict().items()}
+    gen = torch.Generator().manual_seed(1)
+    H, W = args.height, args.width
+    gt = O.synth_depth_gt(1, H, W, args.dataset, gen)
+    focal = O.synth_focal(1, args.dataset)
+
+    def step(h, w):
+        x = torch.randn(1, 3, h, w, generator=gen)
+        feats = enc(x)
+        outs, _ = O.decoder_forward(P, feats, focal, params.max_depth, args.dataset, True)
+        g = gt[:, :, :h, :w]
+        loss = O.silog(outs[4], g, g > (1.0 if args.dataset == "kitti" else 0.1), 0.85)
+        loss.backward()
+    step(64, 128)                        # thread-pool / allocator warm-up on a tiny input
+    t0 = time.time()
+    step(H, W)
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(),
+            "host_cpu_count": os.cpu_count(), "kind": "port",
+            "sample": "1 image %dx%d f32, oracle encoder+decoder fwd+silog+bwd, 1 timed iteration (%.1f s)" % (H, W, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from bts_amd import _lib, profiler
+    from bts_amd.model import BtsModel, silog_loss, weights_init_xavier
+    _lib.load()
+
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    params = NS(encoder=args.encoder, max_depth=80.0 if args.dataset == "kitti" else 10.0, dataset=args.dataset,
+                bts_size=512, decoder_dtype=cdt)
+    torch.manual_seed(0)
+    model = BtsModel(params)
+    model.train()
+    model.decoder.apply(weights_init_xavier)
+    set_misc(model)
+    model.to(dev)
+    if args.channels_last:
+        model.encoder.to(memory_format=torch.channels_last)
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
+                                                        broadcast_buffers=False)
+    opt = torch.optim.AdamW([{"params": [p for p in model.encoder.parameters() if p.requires_grad], "weight_decay": 1e-2},
+                             {"params": list(model.decoder.parameters()), "weight_decay": 0.0}],
+                            lr=1e-4, eps=1e-3, fused=True)
+    crit = silog_loss(0.85)
+    image, focal, gt = make_batch(args, dev, 1234 + rank)
+    if args.channels_last:
+        image = image.contiguous(memory_format=torch.channels_last)
+    mask = gt > (1.0 if args.dataset == "kitti" else 0.1)
+    total_steps = 50 * 1000
+    gstep = [0]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
+            outs = net(image, focal)
+        loss = crit(outs[4], gt, mask)
+        loss.backward()
+        lr = (1e-4 - 1e-5) * (1 - gstep[0] / total_steps) ** 0.9 + 1e-5     # bts_main.py:456-458
+        for g in opt.param_groups:
+            g["lr"] = lr
+        opt.step()
+        gstep[0] += 1
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    prof = None
+    if not args.no_kernel_events and rank == 0:
+        prof = profiler.enable()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.time() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    roof = None
+    if prof is not None:
+        profiler.disable()
+        roof = prof.summary(PEAK[args.dtype], HBM_PEAK_GBS, args.steps)
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "images/sec (train step) DenseNet161-BTS 352x1216",
+            "value": round(args.batch * world * args.steps / elapsed, 3),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%s train step (fwd+silog+bwd+AdamW), %dx%d, %d img/GPU, kitti focal scaling" %
+                       (args.encoder, args.height, args.width, args.batch),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "encoder": "stock PyTorch-ROCm (%s autocast)" % args.dtype, "decoder": "HIP kernels via libbts_amd.so",
+                       "final_loss": round(final_loss, 5)},
+        }
+        if roof is not None:
+            out.update(roof)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,6 +101,18 @@ def load():
 
 def call(name, *args):
     """Invoke an entry point and raise on a non-zero status."""
+    from . import profiler
+    if profiler.ACTIVE is not None:
+        note = profiler.take()
+        if note is not None:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = getattr(load(), name)(*args)
+            e.record()
+            profiler.ACTIVE.add(note[0], note[1], note[2], s, e)
+            if rc != 0:
+                raise BtsAmdError("%s failed: %s (%d)" % (name, ERRORS.get(rc, "?"), rc))
+            return rc
     rc = getattr(load(), name)(*args)
     if name not in _NO_CHECK and rc != 0:
         raise BtsAmdError("%s failed: %s (%d)" % (name, ERRORS.get(rc, "?"), rc))

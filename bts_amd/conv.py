@@ -15,7 +15,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, profiler
 from ._lib import ConvDesc, call, dtype_code, stream_ptr
 from .ops import pad_to, pix_stride, vec_of
 
@@ -44,6 +44,18 @@ def _taps_up():
                     taps.append((oy, ox, a, b))
                     masks.append(sum(1 << (ky * 3 + kx) for ky in kys for kx in kxs))
     return taps, masks
+
+
+def _dn(dtype):
+    return "f32" if dtype == torch.float32 else "bf16"
+
+
+def _tile(cout):      # mirrors launch_fwd() in csrc/conv_igemm.hip
+    return "128x128" if cout > 64 else ("64x256" if cout > 32 else "32x256")
+
+
+def _wtile(cout):     # mirrors launch_wgrad()
+    return "128x128" if cout > 64 else ("64x128k2" if cout > 32 else "32x128k4")
 
 
 class ConvLayer:
@@ -150,6 +162,10 @@ class ConvLayer:
         d.out_scale = out_scale
         d.out_scale_n = out_scale_n.data_ptr() if out_scale_n is not None else None
         d.accumulate = 0
+        if profiler.ACTIVE is not None:
+            M = N * Hx * Wx
+            profiler.note("conv_igemm<%s,%s>" % (_dn(dtype), _tile(self.cout)), "mfma",
+                          2.0 * M * self.nphase * self.T * self.cin * self.cout)
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return out
 
@@ -184,6 +200,10 @@ class ConvLayer:
         d.out_scale = 1.0
         d.out_scale_n = None
         d.accumulate = int(accumulate)
+        if profiler.ACTIVE is not None:
+            cseg = self.seg_channels[seg_index]
+            profiler.note("conv_igemm<%s,%s>" % (_dn(dtype), _tile(gx.shape[3])), "mfma",
+                          2.0 * N * Hg * Wg * len(self.taps) * cseg * self.cout)
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return gx
 
@@ -201,5 +221,8 @@ class ConvLayer:
         d.Hy, d.Wy = dz.shape[1], dz.shape[2]
         d.osc = 2 if self.up else 1
         dwp = torch.zeros((self.cout, self.nphase * self.T, tb["ktot"]), dtype=torch.float32, device=dz.device)
+        if profiler.ACTIVE is not None:
+            profiler.note("conv_wgrad<%s,%s>" % (_dn(dtype), _wtile(self.cout)), "mfma",
+                          2.0 * N * Hx * Wx * self.nphase * self.T * self.cin * self.cout)
         call("bts_conv_wgrad", C.byref(d), C.c_void_p(dz.data_ptr()), pix_stride(dz), C.c_void_p(dwp.data_ptr()), stream_ptr())
         return self.unpack_wgrad(dwp, dtype)

@@ -9,7 +9,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, profiler
 from ._lib import ACT_ELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BtsAmdError, call, dtype_code, stream_ptr  # noqa: F401
 
 
@@ -67,6 +67,8 @@ def lpg_head_fwd(raw, k, max_depth, want_plane=False):
     assert raw.dtype == torch.float32
     depth = torch.empty((B, h * k, w * k), dtype=torch.float32, device=raw.device)
     plane = torch.empty((B, h, w, 4), dtype=torch.float32, device=raw.device) if want_plane else None
+    if profiler.ACTIVE is not None:   # algorithmic bytes: read 3 f32 per cell (stride-4 records: 16 B), write k*k f32
+        profiler.note("lpg_head_fwd<k=%d>" % k, "hbm", B * h * w * (16 + 4 * k * k))
     call("bts_lpg_head_fwd", _p(raw), pix_stride(raw), _p(depth), _p(plane), B, h, w, k, float(max_depth), stream_ptr())
     return (depth, plane) if want_plane else depth
 
@@ -74,6 +76,8 @@ def lpg_head_fwd(raw, k, max_depth, want_plane=False):
 def lpg_head_bwd(raw, grad_depth, k, max_depth, grad_dtype, grad_pad):
     B, h, w, _ = raw.shape
     g = torch.empty((B, h, w, grad_pad), dtype=grad_dtype, device=raw.device)
+    if profiler.ACTIVE is not None:
+        profiler.note("lpg_head_bwd<k=%d>" % k, "hbm", B * h * w * (16 + 4 * k * k + grad_pad * g.element_size()))
     call("bts_lpg_head_bwd", _p(raw), pix_stride(raw), _p(grad_depth), _p(g), dtype_code(grad_dtype), grad_pad, grad_pad,
          B, h, w, k, float(max_depth), stream_ptr())
     return g
