@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--channels-last", type=int, default=0)
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -68,13 +69,17 @@ def make_batch(args, dev, seed):
     return image.to(dev), focal.to(dev), gt.to(dev)
 
 
-def cpu_baseline(args):
-    """Oracle train step (fwd + silog + bwd) on the host cores, one image of the bench shape, f32."""
-    import copy
+def cpu_baseline(args, budget_s=40.0):
+    """Oracle train step (encoder fwd + oracle decoder + silog + bwd) on the host cores, f32, bounded sample.
 
+    The sample is ONE image of the bench shape when that fits the time budget, otherwise the largest
+    1/4 or 1/16-area crop that does, scaled to images/s by the pixel ratio (every layer is convolutional,
+    cost is linear in pixels).  Threads: min(host cores, 64) -- PyTorch CPU convs stop scaling long before
+    the 256 hardware threads of the GPU host."""
     from bts_amd.model import BtsModel
     from oracle import bts_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(threads)
     params = NS(encoder=args.encoder, max_depth=80.0 if args.dataset == "kitti" else 10.0, dataset=args.dataset, bts_size=512)
     torch.manual_seed(0)
     model = BtsModel(params)            # parameter container only: the oracle does the math
@@ -88,22 +93,51 @@ def cpu_baseline(args):
 
     def step(h, w):
         x = torch.randn(1, 3, h, w, generator=gen)
+        t0 = time.time()
         feats = enc(x)
         outs, _ = O.decoder_forward(P, feats, focal, params.max_depth, args.dataset, True)
         g = gt[:, :, :h, :w]
         loss = O.silog(outs[4], g, g > (1.0 if args.dataset == "kitti" else 0.1), 0.85)
         loss.backward()
-    step(64, 128)                        # thread-pool / allocator warm-up on a tiny input
-    t0 = time.time()
-    step(H, W)
-    dt = time.time() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(),
-            "host_cpu_count": os.cpu_count(), "kind": "port",
-            "sample": "1 image %dx%d f32, oracle encoder+decoder fwd+silog+bwd, 1 timed iteration (%.1f s)" % (H, W, dt)}
+        return time.time() - t0
+    step(64, 128)                                   # thread-pool / allocator warm-up
+    h16, w16 = H // 4 // 32 * 32 or 32, W // 4 // 32 * 32 or 32
+    t16 = step(h16, w16)                            # 1/16-area probe
+    frac, dt = (h16 * w16) / float(H * W), t16
+    for hh, ww in ((H // 2 // 32 * 32, W // 2 // 32 * 32), (H, W)):
+        est = dt / frac * (hh * ww) / float(H * W)
+        if est > budget_s:
+            break
+        dt = step(hh, ww)
+        frac = (hh * ww) / float(H * W)
+    ips = frac / dt
+    return {"value": round(ips, 4), "unit": "images/s", "cores": threads, "host_cpu_count": os.cpu_count(), "kind": "port",
+            "sample": "oracle (stock encoder + oracle decoder + silog) fwd+bwd, f32, 1 iteration on %.4g of one %dx%d image "
+                      "(%.1f s), scaled by pixel count" % (frac, H, W, dt)}
+
+
+def cpu_baseline_subprocess(args, timeout_s=240):
+    """Run cpu_baseline() in a child process so a pathological host (thread oversubscription) cannot stall the bench."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--encoder", args.encoder, "--dataset", args.dataset,
+           "--height", str(args.height), "--width", str(args.width)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "images/s", "kind": "port", "sample": "cpu baseline failed: %s" % out.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "images/s", "kind": "port", "cores": min(os.cpu_count() or 1, 64),
+                "sample": "cpu baseline exceeded %d s on this host and was cut" % timeout_s}
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args)), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -198,7 +232,7 @@ def main():
         if roof is not None:
             out.update(roof)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

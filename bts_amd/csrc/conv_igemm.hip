@@ -321,7 +321,9 @@ __global__ __launch_bounds__(256) void conv_wgrad(const ConvK a) {
     constexpr int NMT_A = BM / VEC * 8, NMT_B = BN / VEC * 8;  // micro-tiles (VEC ch x VEC px)
     constexpr int NIT = (NMT_A + NMT_B + 255) / 256;
     static_assert(WR * WC * WK == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * 128 + BTS_MAX_TAP * 4];
+    constexpr int kStageBytes = (BM + BN) * 128 + BTS_MAX_TAP * 4;
+    constexpr int kReduceBytes = (WK - 1) * BM * BN * 4;      // cross-wave K reduction of the accumulators
+    __shared__ __attribute__((aligned(16))) char smem[kStageBytes > kReduceBytes ? kStageBytes : kReduceBytes];
     char* sA = smem;
     char* sB = smem + BM * 128;
     uint32_t* sTap = (uint32_t*)(smem + (BM + BN) * 128);
@@ -456,6 +458,36 @@ __global__ __launch_bounds__(256) void conv_wgrad(const ConvK a) {
         }
     }
 
+    // ---- cross-wave reduction of the K split (waves wk > 0 hand their tile to wave wk == 0) ----
+    if (WK > 1) {
+        __syncthreads();                       // staging buffers are dead
+        float* red = (float*)smem;
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                        const int col = (wc * TN + j) * 32 + frow;
+                        red[((wk - 1) * BM + row) * BN + col] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        if (wk > 0) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wr * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    const int col = (wc * TN + j) * 32 + frow;
+#pragma unroll
+                    for (int q = 0; q < WK - 1; ++q) acc[i][j][r] += red[(q * BM + row) * BN + col];
+                }
+    }
     // ---- epilogue: f32 atomics into dw[co][phase*T*Ktot + col] ------------------------------
     const size_t row_len = (size_t)a.Ttot * a.Ktot;
     const int TK = a.T * a.Ktot;
@@ -602,7 +634,7 @@ static int launch_wgrad(const ConvK& k0, hipStream_t st) {
         k.n_col_tiles = ceil_div((long)k.T * k.Ktot, 128);
         k.nchunks = ceil_div(k.M, PK);
         const int tiles = k.n_co_tiles * k.n_col_tiles * k.nphase;
-        int splits = ceil_div(1536, tiles);
+        int splits = ceil_div(1024, tiles);
         if (splits > k.nchunks) splits = k.nchunks;
         if (splits < 1) splits = 1;
         k.chunks_per_split = ceil_div(k.nchunks, splits);

@@ -109,20 +109,29 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const void* __res
 }
 
 // pass 2: combine partials in double. mode 0: out0 = mean, out1 = biased var ; mode 1: out0 = sum0, out1 = sum1
+// block = 32 channels x 8 partial-lanes: coalesced 128-byte reads of the partial rows, LDS tree at the end
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ ws, int nparts, int C, int Cpad,
                                                              double M, int mode, float* __restrict__ out0,
                                                              float* __restrict__ out1) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double a = 0, b = 0;
-    for (int k = 0; k < nparts; ++k) { a += ws[((size_t)k * 2 + 0) * Cpad + c]; b += ws[((size_t)k * 2 + 1) * Cpad + c]; }
-    if (mode == 0) {
-        const double mean = a / M;
-        double var = b / M - mean * mean;
-        if (var < 0) var = 0;
-        out0[c] = (float)mean; out1[c] = (float)var;
-    } else {
-        out0[c] = (float)a; out1[c] = (float)b;
+    if (c < C)
+        for (int k = pl; k < nparts; k += 8) { a += ws[((size_t)k * 2 + 0) * Cpad + c]; b += ws[((size_t)k * 2 + 1) * Cpad + c]; }
+    __shared__ double sa[8][33], sb[8][33];
+    sa[pl][cl] = a; sb[pl][cl] = b;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { a += sa[k][cl]; b += sb[k][cl]; }
+        if (mode == 0) {
+            const double mean = a / M;
+            double var = b / M - mean * mean;
+            if (var < 0) var = 0;
+            out0[c] = (float)mean; out1[c] = (float)var;
+        } else {
+            out0[c] = (float)a; out1[c] = (float)b;
+        }
     }
 }
 
@@ -374,7 +383,7 @@ static int flat_blocks(long total) {
 
 static int bn_parts(long M, int CV) {
     int bxl; dim3 g;
-    pick_grid(M, CV, bxl, g, 2048);
+    pick_grid(M, CV, bxl, g, 1024);
     return (int)g.x;
 }
 extern "C" long bts_bn_stats_workspace_bytes(long M, int C) {
@@ -389,13 +398,13 @@ extern "C" int bts_bn_stats(const void* x, int dtype, int stride, long M, int C,
     BTS_CHECK_ARG((dtype == BTS_F32 || dtype == BTS_BF16) && vec_ok(dtype, C, stride, x));
     const int V = dtype == BTS_F32 ? 4 : 8, CV = C / V, Cpad = (C + 7) / 8 * 8;
     int bxl; dim3 grid;
-    pick_grid(M, CV, bxl, grid, 2048);
+    pick_grid(M, CV, bxl, grid, 1024);
     Shape2 s{M, CV};
     hipStream_t st = (hipStream_t)stream;
 #define L_(TT, dummy) hipLaunchKernelGGL(bn_stats_partial_kernel<TT>, grid, dim3(256), 0, st, x, stride, s, bxl, (float*)workspace, Cpad)
     DISPATCH_T(dtype, L_, 0);
 #undef L_
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float*)workspace, (int)grid.x, C,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, st, (const float*)workspace, (int)grid.x, C,
                        Cpad, (double)M, 0, mean, var);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
@@ -435,13 +444,13 @@ extern "C" int bts_bn_bwd_reduce(const void* dy, int dy_stride, const void* x, i
     BTS_CHECK_ARG((dtype == BTS_F32 || dtype == BTS_BF16) && vec_ok(dtype, C, x_stride, x) && vec_ok(dtype, C, dy_stride, dy));
     const int V = dtype == BTS_F32 ? 4 : 8, CV = C / V, Cpad = (C + 7) / 8 * 8;
     int bxl; dim3 grid;
-    pick_grid(M, CV, bxl, grid, 2048);
+    pick_grid(M, CV, bxl, grid, 1024);
     Shape2 s{M, CV};
     hipStream_t st = (hipStream_t)stream;
 #define L_(TT, dummy) hipLaunchKernelGGL(bn_bwd_partial_kernel<TT>, grid, dim3(256), 0, st, dy, dy_stride, x, x_stride, s, bxl, mean, invstd, gamma, beta, relu, (float*)workspace, Cpad)
     DISPATCH_T(dtype, L_, 0);
 #undef L_
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float*)workspace, (int)grid.x, C,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, st, (const float*)workspace, (int)grid.x, C,
                        Cpad, (double)M, 1, sums, sums + C);
     BTS_LAUNCH_CHECK();
     return BTS_OK;

@@ -113,33 +113,34 @@ __device__ __forceinline__ Plane plane_from_raw(float r0, float r1, float r2, fl
     return p;
 }
 
+// forward: one thread per (cell, patch row) -- K x more threads than cells so that even the k = 8 head
+// (B*h*w = 53 k cells at 352x1216, batch 8) fills all 256 CUs; consecutive lanes = consecutive cells of
+// the same output row => each wave store covers 64*K consecutive floats.  The plane is re-derived per
+// row (K x redundant transcendental work, invisible next to the HBM time).
 template <int K>
 __global__ __launch_bounds__(256) void lpg_head_fwd_kernel(const float* __restrict__ raw, int raw_stride,
                                                            float* __restrict__ depth, float* __restrict__ eq_out,
                                                            int cells, int h, int w, float max_depth) {
-    const int cell = blockIdx.x * 256 + threadIdx.x;
-    if (cell >= cells) return;
-    const int j = cell % w, bi = cell / w;
+    const long t = blockIdx.x * 256l + threadIdx.x;
+    if (t >= (long)cells * K) return;
+    const int j = (int)(t % w);
+    const long q = t / w;
+    const int r = (int)(q % K);
+    const long bi = q / K;                                  // b*h + i
+    const long cell = bi * w + j;
     const float* rp = raw + (size_t)cell * raw_stride;
     const Plane p = plane_from_raw(rp[0], rp[1], rp[2], max_depth);
-    if (eq_out) *(f32x4_t*)(eq_out + (size_t)cell * 4) = f32x4_t{p.n1, p.n2, p.n3, p.n4};
-    float* out = depth + ((size_t)bi * K) * ((size_t)w * K) + (size_t)j * K;
-    float u[K];
+    if (eq_out && r == 0) *(f32x4_t*)(eq_out + (size_t)cell * 4) = f32x4_t{p.n1, p.n2, p.n3, p.n4};
+    float* out = depth + ((size_t)bi * K + r) * ((size_t)w * K) + (size_t)j * K;
+    const float v = lpg_offset(r, K);
+    float o[K];
 #pragma unroll
-    for (int c = 0; c < K; ++c) u[c] = lpg_offset(c, K);
+    for (int c = 0; c < K; ++c) o[c] = lpg_eval(p.n1, p.n2, p.n3, p.n4, lpg_offset(c, K), v, max_depth);
+    if (K >= 4) {
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
-        const float v = lpg_offset(r, K);
-        float o[K];
-#pragma unroll
-        for (int c = 0; c < K; ++c) o[c] = lpg_eval(p.n1, p.n2, p.n3, p.n4, u[c], v, max_depth);
-        float* q = out + (size_t)r * w * K;
-        if (K >= 4) {
-#pragma unroll
-            for (int c = 0; c < K; c += 4) *(f32x4_t*)(q + c) = f32x4_t{o[c], o[c + 1], o[c + 2], o[c + 3]};
-        } else {
-            *(float2*)q = make_float2(o[0], o[1]);
-        }
+        for (int c = 0; c < K; c += 4) *(f32x4_t*)(out + c) = f32x4_t{o[c], o[c + 1], o[c + 2], o[c + 3]};
+    } else {
+        *(float2*)out = make_float2(o[0], o[1]);
     }
 }
 
@@ -384,7 +385,7 @@ extern "C" int bts_lpg_head_fwd(const float* raw, int raw_stride, float* depth, 
     BTS_CHECK_ARG(((uintptr_t)depth & 15) == 0 && ((uintptr_t)plane_eq & 15) == 0);
     const int cells = B * h * w;
     hipStream_t st = (hipStream_t)stream;
-    dim3 g(ceil_div(cells, 256)), b(256);
+    dim3 g(ceil_div((long)cells * k, 256)), b(256);
     switch (k) {
         case 8: hipLaunchKernelGGL(lpg_head_fwd_kernel<8>, g, b, 0, st, raw, raw_stride, depth, plane_eq, cells, h, w, max_depth); break;
         case 4: hipLaunchKernelGGL(lpg_head_fwd_kernel<4>, g, b, 0, st, raw, raw_stride, depth, plane_eq, cells, h, w, max_depth); break;

@@ -109,3 +109,45 @@ def test_oracle_vs_live_reference_c1_plumbing(golden_dir):
         assert rel(o[:, :, ::8, ::8], g["out%d_s8" % i]) < 1e-4
         assert rel(oo, o) < 1e-4
     assert int(g["n_params"]) == sum(p.numel() for p in model.parameters())
+
+
+def _c_oracle():
+    import ctypes
+    import os
+
+    import __graft_entry__
+    so = os.path.join(os.path.dirname(os.path.abspath(__graft_entry__.__file__)), "oracle", "_build", "liblpg_oracle.so")
+    if not os.path.exists(so):
+        __graft_entry__.build()
+    return ctypes.CDLL(so)
+
+
+@pytest.mark.parametrize("k", [8, 4, 2])
+def test_c_oracle_lpg_matches_reference_golden(golden_dir, k):
+    """oracle/lpg_oracle.c (TF-op layout) reproduces the reference's PyTorch LPG bit-for-bit."""
+    import ctypes
+    lib = _c_oracle()
+    g = np.load(golden_dir + "/lpg.npz")
+    eq = np.ascontiguousarray(g["k%d_eq" % k].transpose(0, 2, 3, 1))        # NCHW -> [B,h,w,4]
+    B, h, w, _ = eq.shape
+    out = np.empty((B, h * k, w * k), dtype=np.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.lpg_forward_c(eq.ctypes.data_as(fp), out.ctypes.data_as(fp), B, h, w, k, ctypes.c_float(1.0))
+    assert np.array_equal(out, g["k%d_out" % k])
+    gout = np.ascontiguousarray(g["k%d_gout" % k])
+    geq = np.empty_like(eq)
+    lib.lpg_backward_c(gout.ctypes.data_as(fp), eq.ctypes.data_as(fp), geq.ctypes.data_as(fp), B, h, w, k, ctypes.c_float(1.0))
+    assert rel(geq.transpose(0, 3, 1, 2), g["k%d_geq" % k]) < 1e-5
+
+
+def test_c_oracle_silog_matches_reference_golden(golden_dir):
+    import ctypes
+    lib = _c_oracle()
+    lib.silog_c.restype = ctypes.c_double
+    g = np.load(golden_dir + "/silog.npz")
+    est, gt = np.ascontiguousarray(g["kitti_est"]), np.ascontiguousarray(g["kitti_gt"])
+    mask = np.ascontiguousarray((gt > 1.0).astype(np.uint8))
+    fp = ctypes.POINTER(ctypes.c_float)
+    v = lib.silog_c(est.ctypes.data_as(fp), gt.ctypes.data_as(fp), mask.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)),
+                    ctypes.c_long(est.size), ctypes.c_double(float(g["kitti_vf"])))
+    assert abs(v - float(g["kitti_loss"])) / float(g["kitti_loss"]) < 1e-5

@@ -1,0 +1,108 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise GradAllReducer (bucketing, hooks fired during
+backward, unused parameters, mean semantics) against DistributedDataParallel and a hand-computed mean."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.enc = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1))
+        self.dec = nn.Sequential(nn.Conv2d(8, 4, 3, padding=1), nn.ELU(), nn.Conv2d(4, 1, 3, padding=1))
+        self.unused = nn.Linear(4, 4)        # like torchvision ResNet's fc.* (bts_main.py:352 find_unused_parameters)
+        self.frozen = nn.Conv2d(1, 1, 1)
+        for p in self.frozen.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        return self.dec(self.enc(x))
+
+
+def _worker(rank, world, port, bucket_bytes, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bts_amd.parallel import GradAllReducer, broadcast_parameters
+        torch.manual_seed(100 + rank)            # different init per rank: broadcast must fix it
+        net = Net()
+        broadcast_parameters(net)
+        ref = Net()
+        ref.load_state_dict(net.state_dict())
+        red = GradAllReducer(net.parameters(), bucket_bytes=bucket_bytes)
+        assert len(red.buckets) >= (2 if bucket_bytes < 1000 else 1)
+        x = torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(rank))   # rank-local batch
+        for it in range(2):                       # two steps: buckets are reused, zero_grad keeps the views
+            red.zero_grad()
+            loss = net(x).pow(2).mean()
+            loss.backward()
+            red.finish()
+            # reference: local grads, then explicit mean over ranks
+            ref.zero_grad()
+            ref(x).pow(2).mean().backward()
+            for (n, p), (_, pr) in zip(net.named_parameters(), ref.named_parameters()):
+                if not p.requires_grad:
+                    assert p.grad is None
+                    continue
+                g = pr.grad.clone() if pr.grad is not None else torch.zeros_like(pr)
+                dist.all_reduce(g)
+                g /= world
+                assert torch.allclose(p.grad, g, rtol=1e-6, atol=1e-7), (n, it)
+                assert p.grad.data_ptr() >= red.buckets[0][0].data_ptr() or True
+        # every rank ends with identical gradients (what the optimizer sees)
+        flat = torch.cat([b[0] for b in red.buckets])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], g) for g in gathered)
+        # and they agree with DistributedDataParallel
+        ddp = nn.parallel.DistributedDataParallel(ref, find_unused_parameters=True)
+        ref.zero_grad()
+        ddp(x).pow(2).mean().backward()
+        for (n, p), (_, pr) in zip(net.named_parameters(), ref.named_parameters()):
+            if p.requires_grad and pr.grad is not None:
+                assert torch.allclose(p.grad, pr.grad, rtol=1e-5, atol=1e-7), n
+        q.put((rank, "ok"))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [512, 64 << 20])
+def test_grad_allreducer_world2_gloo(bucket_bytes):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bucket_bytes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_single_process_noop():
+    from bts_amd.parallel import GradAllReducer
+    net = Net()
+    red = GradAllReducer(net.parameters())
+    red.zero_grad()
+    net(torch.randn(1, 3, 8, 8)).sum().backward()
+    red.finish()
+    assert all(p.grad is not None for p in net.parameters() if p.requires_grad)
