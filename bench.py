@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--channels-last", type=int, default=0)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--graph", type=int, default=1, help="capture the train step in a hipGraph (N=1 only; falls back to eager)")
+    ap.add_argument("--cudnn-benchmark", type=int, default=0)
     return ap.parse_args()
 
 
@@ -166,9 +168,12 @@ def main():
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
                                                         broadcast_buffers=False)
+    use_graph = bool(args.graph) and world == 1
+    torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
+    lr_t = torch.tensor(1e-4, device=dev)      # capturable optimizers read lr from a device tensor
     opt = torch.optim.AdamW([{"params": [p for p in model.encoder.parameters() if p.requires_grad], "weight_decay": 1e-2},
                              {"params": list(model.decoder.parameters()), "weight_decay": 0.0}],
-                            lr=1e-4, eps=1e-3, fused=True)
+                            lr=lr_t if use_graph else 1e-4, eps=1e-3, fused=True, capturable=use_graph)
     crit = silog_loss(0.85)
     image, focal, gt = make_batch(args, dev, 1234 + rank)
     if args.channels_last:
@@ -177,23 +182,61 @@ def main():
     total_steps = 50 * 1000
     gstep = [0]
 
-    def step():
+    def poly_lr():
+        return (1e-4 - 1e-5) * (1 - gstep[0] / total_steps) ** 0.9 + 1e-5     # bts_main.py:456-458
+
+    def step_body():
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
             outs = net(image, focal)
         loss = crit(outs[4], gt, mask)
         loss.backward()
-        lr = (1e-4 - 1e-5) * (1 - gstep[0] / total_steps) ** 0.9 + 1e-5     # bts_main.py:456-458
-        for g in opt.param_groups:
-            g["lr"] = lr
         opt.step()
+        return loss
+
+    def step_eager():
+        lr = poly_lr()
+        for g in opt.param_groups:
+            if use_graph:
+                g["lr"].fill_(lr)
+            else:
+                g["lr"] = lr
+        loss = step_body()
         gstep[0] += 1
         return loss
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):
+        step_eager()
+    graph, static_loss, graph_note = None, None, "eager"
+    if use_graph:
+        try:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step_eager()                       # one step on the capture stream (allocator warm-up)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = step_body()
+            graph_note = "hipGraph replay of the whole step (fwd+loss+bwd+AdamW)"
+        except Exception as e:   # noqa: BLE001
+            graph, graph_note = None, "eager (graph capture failed: %s)" % str(e)[:120]
+            torch.cuda.synchronize()
+
+    def step():
+        if graph is None:
+            return step_eager()
+        lr_t.fill_(poly_lr())
+        graph.replay()
+        gstep[0] += 1
+        return static_loss
+
+    for _ in range(2):
         step()
     prof = None
-    if not args.no_kernel_events and rank == 0:
+    if not args.no_kernel_events and rank == 0 and graph is None:
         prof = profiler.enable()
     if world > 1:
         dist.barrier()
@@ -209,12 +252,18 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    final_loss = float(loss.item())
+    if graph is not None and not args.no_kernel_events and rank == 0:
+        # events cannot be recorded inside a graph replay: time the same kernels over the same number of
+        # eager steps right after the timed region (same process, same buffers, same clocks)
+        prof = profiler.enable()
+        for _ in range(args.steps):
+            step_eager()
+        torch.cuda.synchronize()
     roof = None
     if prof is not None:
         profiler.disable()
         roof = prof.summary(PEAK[args.dtype], HBM_PEAK_GBS, args.steps)
-    final_loss = float(loss.item())
-
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         out = {
@@ -226,7 +275,7 @@ def main():
             "config": {"workload": "%s train step (fwd+silog+bwd+AdamW), %dx%d, %d img/GPU, kitti focal scaling" %
                        (args.encoder, args.height, args.width, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "encoder": "stock PyTorch-ROCm (%s autocast)" % args.dtype, "decoder": "HIP kernels via libbts_amd.so",
+                       "encoder": "stock PyTorch-ROCm (%s autocast)" % args.dtype, "decoder": "HIP kernels via libbts_amd.so", "launch": graph_note,
                        "final_loss": round(final_loss, 5)},
         }
         if roof is not None:

@@ -50,8 +50,8 @@ def _dn(dtype):
     return "f32" if dtype == torch.float32 else "bf16"
 
 
-def _tile(cout):      # mirrors launch_fwd() in csrc/conv_igemm.hip
-    return "128x128" if cout > 64 else ("64x256" if cout > 32 else "32x256")
+def _tile(cout):      # mirrors launch_fwd() in csrc/conv_igemm.hip (LDS-DMA variants)
+    return "128x128" if cout > 64 else ("64x128" if cout > 32 else "32x256")
 
 
 def _wtile(cout):     # mirrors launch_wgrad()
@@ -164,7 +164,7 @@ class ConvLayer:
         d.accumulate = 0
         if profiler.ACTIVE is not None:
             M = N * Hx * Wx
-            profiler.note("conv_igemm<%s,%s>" % (_dn(dtype), _tile(self.cout)), "mfma",
+            profiler.note("conv_igemm_dma<%s,%s>" % (_dn(dtype), _tile(self.cout)), "mfma",
                           2.0 * M * self.nphase * self.T * self.cin * self.cout)
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return out
@@ -202,7 +202,7 @@ class ConvLayer:
         d.accumulate = int(accumulate)
         if profiler.ACTIVE is not None:
             cseg = self.seg_channels[seg_index]
-            profiler.note("conv_igemm<%s,%s>" % (_dn(dtype), _tile(gx.shape[3])), "mfma",
+            profiler.note("conv_igemm_dma<%s,%s>" % (_dn(dtype), _tile(gx.shape[3])), "mfma",
                           2.0 * N * Hg * Wg * len(self.taps) * cseg * self.cout)
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return gx

@@ -14,6 +14,8 @@
 //
 // Replaces (as hand-written kernels) every Conv2d of pytorch/bts.py:51-80, 91-108, 153-194 and
 // torch.cat / F.interpolate(nearest) around them; see include/bts_amd.h for the descriptor.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -99,6 +101,73 @@ __device__ __forceinline__ void pick_seg(const ConvK& a, int cv, const char*& sp
             sp = a.seg_ptr[s];
             sst = a.seg_stride[s];
             coff = cv - a.seg_cum[s];
+        }
+    }
+}
+
+template <typename T, int WR, int WC, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16_t (&acc)[TM][TN], int co_tile, int px_tile, int phase,
+                                              int wr, int wc, int frow, int fk) {
+    constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+    // ---- epilogue: lanes <-> pixels, registers <-> channels -------------------------------
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int m = px_tile * BN + (wc * TN + j) * 32 + frow;
+        if (m >= a.M) continue;
+        const uint32_t n = fdiv(m, a.fd_hw);
+        const uint32_t rem = m - n * (uint32_t)(a.Hg * a.Wg);
+        const uint32_t y = fdiv(rem, a.fd_w);
+        const uint32_t x = rem - y * a.Wg;
+        const size_t opix = ((size_t)n * a.Hy + (y * a.osc + (phase >> 1))) * a.Wy + (x * a.osc + (phase & 1));
+        float sc = a.out_scale;
+        if (a.out_scale_n) sc *= a.out_scale_n[n];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = co_tile * BM + (wr * TM + i) * 32 + 8 * q + 4 * fk;
+                if (co >= a.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[i][j][4 * q + e];
+                    if (a.act == BTS_ACT_ELU) t = act_elu(t);
+                    else if (a.act == BTS_ACT_SIGMOID) t = act_sigmoid(t);
+                    else if (a.act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
+                    v[e] = t * sc;
+                }
+                const size_t o = opix * a.y_stride + co;
+                if (a.vec_store) {
+                    if (a.y_f32) {
+                        float* p = (float*)a.y + o;
+                        f32x4_t t = {v[0], v[1], v[2], v[3]};
+                        if (a.accumulate) { f32x4_t old = *(f32x4_t*)p; t += old; }
+                        *(f32x4_t*)p = t;
+                    } else {
+                        uint16_t* p = (uint16_t*)a.y + o;
+                        if (a.accumulate) {
+                            u32x2_t old = *(u32x2_t*)p;
+                            v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                            v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+                        }
+                        u32x2_t t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *(u32x2_t*)p = t;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e >= a.Cout) break;
+                        if (a.y_f32) {
+                            float* p = (float*)a.y + o + e;
+                            *p = a.accumulate ? *p + v[e] : v[e];
+                        } else {
+                            uint16_t* p = (uint16_t*)a.y + o + e;
+                            const float t = a.accumulate ? bf16_bits_to_f32(*p) + v[e] : v[e];
+                            *p = (uint16_t)f32_to_bf16_bits(t);
+                        }
+                    }
+                }
+            }
         }
     }
 }
@@ -222,67 +291,133 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK a) {
         }
     }
 
-    // ---- epilogue: lanes <-> pixels, registers <-> channels -------------------------------
+    conv_epilogue<T, WR, WC, TM, TN>(a, acc, co_tile, px_tile, phase, wr, wc, frow, fk);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / data-gradient kernel, LDS-DMA staging (global_load_lds_dwordx4, 16 B per lane)
+//
+// Same math and LDS image as conv_igemm, but tiles go HBM -> LDS directly (no staging VGPRs, no
+// ds_write pass) into a double buffer, with ONE barrier per K chunk: the DMA of chunk c+1 is in
+// flight while the MFMAs of chunk c run.  The DMA destination is lane-linear (wave-uniform base +
+// lane*16 B), so the XOR swizzle of the LDS image is applied to the per-lane SOURCE address instead
+// (lane (row, pc) fetches logical chunk pc ^ ((row>>1)&7)); padding / out-of-image taps read a
+// 64-byte zero page instead of being predicated.
+// ------------------------------------------------------------------------------------------------
+__device__ const uint32_t kZeroPage[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <typename T, int WR, int WC, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_igemm_dma(const ConvK a) {
+    constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+    constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int VEC = T::kVec, ES = T::kBytes;
+    constexpr int BUF = (BM + BN) * 128;
+    static_assert(WR * WC == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF + BTS_MAX_TAP * 4];
+    uint32_t* sTap = (uint32_t*)(smem + 2 * BUF);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int phase = blockIdx.y;
+    const int L = remap_xcd(blockIdx.x, a.n_px_tiles * a.n_co_tiles);
+    const int co_tile = L % a.n_co_tiles, px_tile = L / a.n_co_tiles;
+    if (tid < BTS_MAX_TAP) sTap[tid] = a.taps[tid];
+
+    const int pc = tid & 7, srow = tid >> 3;          // physical chunk / row this lane's DMA lands in
+    const int vec = pc ^ ((srow >> 1) & 7);           // logical K chunk it must fetch (rows differ by 32*i: same swizzle)
+    int py[RB], px[RB], pn[RB];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int m = px_tile * BN + (wc * TN + j) * 32 + frow;
-        if (m >= a.M) continue;
-        const uint32_t n = fdiv(m, a.fd_hw);
-        const uint32_t rem = m - n * (uint32_t)(a.Hg * a.Wg);
-        const uint32_t y = fdiv(rem, a.fd_w);
-        const uint32_t x = rem - y * a.Wg;
-        const size_t opix = ((size_t)n * a.Hy + (y * a.osc + (phase >> 1))) * a.Wy + (x * a.osc + (phase & 1));
-        float sc = a.out_scale;
-        if (a.out_scale_n) sc *= a.out_scale_n[n];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int co = co_tile * BM + (wr * TM + i) * 32 + 8 * q + 4 * fk;
-                if (co >= a.Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[i][j][4 * q + e];
-                    if (a.act == BTS_ACT_ELU) t = act_elu(t);
-                    else if (a.act == BTS_ACT_SIGMOID) t = act_sigmoid(t);
-                    else if (a.act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
-                    v[e] = t * sc;
-                }
-                const size_t o = opix * a.y_stride + co;
-                if (a.vec_store) {
-                    if (a.y_f32) {
-                        float* p = (float*)a.y + o;
-                        f32x4_t t = {v[0], v[1], v[2], v[3]};
-                        if (a.accumulate) { f32x4_t old = *(f32x4_t*)p; t += old; }
-                        *(f32x4_t*)p = t;
-                    } else {
-                        uint16_t* p = (uint16_t*)a.y + o;
-                        if (a.accumulate) {
-                            u32x2_t old = *(u32x2_t*)p;
-                            v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
-                            v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
-                        }
-                        u32x2_t t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                        *(u32x2_t*)p = t;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (co + e >= a.Cout) break;
-                        if (a.y_f32) {
-                            float* p = (float*)a.y + o + e;
-                            *p = a.accumulate ? *p + v[e] : v[e];
-                        } else {
-                            uint16_t* p = (uint16_t*)a.y + o + e;
-                            const float t = a.accumulate ? bf16_bits_to_f32(*p) + v[e] : v[e];
-                            *p = (uint16_t)f32_to_bf16_bits(t);
-                        }
-                    }
-                }
-            }
+    for (int i = 0; i < RB; ++i) {
+        const int m = px_tile * BN + srow + 32 * i;
+        if (m < a.M) {
+            const uint32_t n = fdiv(m, a.fd_hw);
+            const uint32_t rem = m - n * (uint32_t)(a.Hg * a.Wg);
+            const uint32_t y = fdiv(rem, a.fd_w);
+            py[i] = (int)y;
+            px[i] = (int)(rem - y * a.Wg);
+            pn[i] = (int)n;
+        } else {
+            py[i] = px[i] = 0;
+            pn[i] = -1;
         }
     }
+    const int TKV = a.T * a.KV;
+    const int nchunks = (TKV + 7) >> 3;
+    const size_t w_phase_off = (size_t)phase * a.T * a.Ktot;
+    const size_t w_row = (size_t)a.Ttot * a.Ktot;
+    const char* zero = (const char*)kZeroPage;
+
+    int tap = 0, cv = vec;
+    while (cv >= a.KV) { cv -= a.KV; ++tap; }
+    __syncthreads();  // tap table visible
+
+    auto issue_chunk = [&](int chunk, int buf) {
+        char* sA = smem + buf * BUF;
+        char* sB = sA + BM * 128;
+        const int kv = chunk * 8 + vec;
+        const bool kok = kv < TKV;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int co = co_tile * BM + srow + 32 * i;
+            const char* src = zero;
+            if (kok && co < a.Cout) src = a.w + ((size_t)co * w_row + w_phase_off + (size_t)kv * VEC) * ES;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+        }
+        int dy = 0, dx = 0, ioy = 0, iox = 0;
+        const char* sp; int sst, coff;
+        pick_seg(a, cv, sp, sst, coff);
+        if (kok) decode_tap(sTap[phase * a.T + tap], dy, dx, ioy, iox);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int yy = py[i] + dy, xx = px[i] + dx;
+            const char* src = zero;
+            if (kok && pn[i] >= 0 && (unsigned)yy < (unsigned)a.Hg && (unsigned)xx < (unsigned)a.Wg) {
+                const size_t pix = ((size_t)pn[i] * a.Hx + (yy * a.isc + ioy)) * a.Wx + (xx * a.isc + iox);
+                src = sp + (pix * sst + (size_t)coff * VEC) * ES;
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+        }
+        cv += 8;
+        while (cv >= a.KV) { cv -= a.KV; ++tap; }
+    };
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wr = wave / WC, wc = wave % WC;
+    const int frow = lane & 31, fk = lane >> 5;
+
+    issue_chunk(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cur = chunk & 1;
+        if (chunk + 1 < nchunks) issue_chunk(chunk + 1, cur ^ 1);
+        const char* sA = smem + cur * BUF;
+        const char* sB = sA + BM * 128;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4_t fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4_t*)(sA + lds_off((wr * TM + i) * 32 + frow, 2 * s + fk));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *(const u32x4_t*)(sB + lds_off((wc * TN + j) * 32 + frow, 2 * s + fk));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next chunk has landed
+        __syncthreads();                                     // everyone's has, and everyone is done reading `cur`
+    }
+    conv_epilogue<T, WR, WC, TM, TN>(a, acc, co_tile, px_tile, phase, wr, wc, frow, fk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -609,6 +744,15 @@ static int fill_common(const bts_conv_desc_t* d, ConvK& k) {
     return BTS_OK;
 }
 
+// Staging variant: LDS-DMA (default) or register staging (BTS_CONV_STAGING=reg, kept for A/B measurements).
+static bool use_lds_dma() {
+    static const int v = [] {
+        const char* e = getenv("BTS_CONV_STAGING");
+        return (e && e[0] == 'r') ? 0 : 1;
+    }();
+    return v != 0;
+}
+
 template <typename T>
 static int launch_fwd(const ConvK& k0, hipStream_t st) {
     ConvK k = k0;
@@ -618,9 +762,15 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
         dim3 grid(k.n_co_tiles * k.n_px_tiles, k.nphase);
         hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, k);
     };
-    if (k.Cout > 64) go(conv_igemm<T, 2, 2, 2, 2>, 128, 128);
-    else if (k.Cout > 32) go(conv_igemm<T, 1, 4, 2, 2>, 64, 256);
-    else go(conv_igemm<T, 1, 4, 1, 2>, 32, 256);
+    if (use_lds_dma()) {
+        if (k.Cout > 64) go(conv_igemm_dma<T, 2, 2, 2, 2>, 128, 128);
+        else if (k.Cout > 32) go(conv_igemm_dma<T, 1, 4, 2, 1>, 64, 128);   // 2 x 24 KB LDS: 3 blocks/CU
+        else go(conv_igemm_dma<T, 1, 4, 1, 2>, 32, 256);
+    } else {
+        if (k.Cout > 64) go(conv_igemm<T, 2, 2, 2, 2>, 128, 128);
+        else if (k.Cout > 32) go(conv_igemm<T, 1, 4, 2, 2>, 64, 256);
+        else go(conv_igemm<T, 1, 4, 1, 2>, 32, 256);
+    }
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }
