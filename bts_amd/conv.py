@@ -50,8 +50,11 @@ def _dn(dtype):
     return "f32" if dtype == torch.float32 else "bf16"
 
 
-def _tile(cout):      # mirrors launch_fwd() in csrc/conv_igemm.hip (LDS-DMA variants)
-    return "128x128" if cout > 64 else ("64x128" if cout > 32 else "32x256")
+def _tile(cout, M=0, nphase=1):      # mirrors launch_fwd() in csrc/conv_igemm.hip (LDS-DMA variants)
+    if cout > 64:
+        big = ((M + 255) // 256) * ((cout + 127) // 128) * nphase >= 384
+        return "128x256x3" if big else "128x128x3"
+    return "64x128x3" if cout > 32 else "32x256x2"
 
 
 def _wtile(cout):     # mirrors launch_wgrad()
@@ -164,7 +167,7 @@ class ConvLayer:
         d.accumulate = 0
         if profiler.ACTIVE is not None:
             M = N * Hx * Wx
-            profiler.note("conv_igemm_dma<%s,%s>" % (_dn(dtype), _tile(self.cout)), "mfma",
+            profiler.note("conv_igemm_dma<%s,%s>" % (_dn(dtype), _tile(self.cout, M, self.nphase)), "mfma",
                           2.0 * M * self.nphase * self.T * self.cin * self.cout)
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return out
@@ -202,7 +205,7 @@ class ConvLayer:
         d.accumulate = int(accumulate)
         if profiler.ACTIVE is not None:
             cseg = self.seg_channels[seg_index]
-            profiler.note("conv_igemm_dma<%s,%s>" % (_dn(dtype), _tile(gx.shape[3])), "mfma",
+            profiler.note("conv_igemm_dma<%s,%s>" % (_dn(dtype), _tile(gx.shape[3], N * Hg * Wg, 1)), "mfma",
                           2.0 * N * Hg * Wg * len(self.taps) * cseg * self.cout)
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return gx

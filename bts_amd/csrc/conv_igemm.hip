@@ -309,15 +309,23 @@ __device__ const uint32_t kZeroPage[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <typename T, int WR, int WC, int TM, int TN>
-__global__ __launch_bounds__(256) void conv_igemm_dma(const ConvK a) {
+// NS-stage pipeline: the DMA of chunk c+NS-1 is issued right after the barrier that retires chunk c-1's
+// buffer; a counted s_waitcnt vmcnt((NS-2)*G) (G = DMA instructions per thread per chunk) retires
+// exactly chunk c's group and leaves the younger groups in flight ACROSS the raw s_barrier (a plain
+// __syncthreads() would drain them: hipcc emits vmcnt(0) in front of it while an LDS-DMA is pending).
+template <typename T, int WR, int WC, int TM, int TN, int NS>
+__global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
+    constexpr int NW = WR * WC;                       // waves per workgroup
     constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
-    constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int RP = 8 * NW;                        // tile rows covered by one DMA pass of the workgroup
+    constexpr int RA = BM / RP, RB = BN / RP;
+    constexpr int G = RA + RB;
     constexpr int VEC = T::kVec, ES = T::kBytes;
     constexpr int BUF = (BM + BN) * 128;
-    static_assert(WR * WC == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF + BTS_MAX_TAP * 4];
-    uint32_t* sTap = (uint32_t*)(smem + 2 * BUF);
+    static_assert(BM % RP == 0 && BN % RP == 0, "tile rows must be a multiple of the DMA pass");
+    static_assert((NS - 2) * G <= 63, "vmcnt range");
+    __shared__ __attribute__((aligned(16))) char smem[NS * BUF + BTS_MAX_TAP * 4];
+    uint32_t* sTap = (uint32_t*)(smem + NS * BUF);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int phase = blockIdx.y;
@@ -326,11 +334,11 @@ __global__ __launch_bounds__(256) void conv_igemm_dma(const ConvK a) {
     if (tid < BTS_MAX_TAP) sTap[tid] = a.taps[tid];
 
     const int pc = tid & 7, srow = tid >> 3;          // physical chunk / row this lane's DMA lands in
-    const int vec = pc ^ ((srow >> 1) & 7);           // logical K chunk it must fetch (rows differ by 32*i: same swizzle)
+    const int vec = pc ^ ((srow >> 1) & 7);           // logical K chunk it must fetch (rows differ by RP*i: same swizzle)
     int py[RB], px[RB], pn[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const int m = px_tile * BN + srow + 32 * i;
+        const int m = px_tile * BN + srow + RP * i;
         if (m < a.M) {
             const uint32_t n = fdiv(m, a.fd_hw);
             const uint32_t rem = m - n * (uint32_t)(a.Hg * a.Wg);
@@ -353,6 +361,8 @@ __global__ __launch_bounds__(256) void conv_igemm_dma(const ConvK a) {
     while (cv >= a.KV) { cv -= a.KV; ++tap; }
     __syncthreads();  // tap table visible
 
+    // always issues exactly G DMA instructions per thread (chunks past the end fetch the zero page),
+    // so the vmcnt arithmetic below is uniform
     auto issue_chunk = [&](int chunk, int buf) {
         char* sA = smem + buf * BUF;
         char* sB = sA + BM * 128;
@@ -360,10 +370,10 @@ __global__ __launch_bounds__(256) void conv_igemm_dma(const ConvK a) {
         const bool kok = kv < TKV;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int co = co_tile * BM + srow + 32 * i;
+            const int co = co_tile * BM + srow + RP * i;
             const char* src = zero;
             if (kok && co < a.Cout) src = a.w + ((size_t)co * w_row + w_phase_off + (size_t)kv * VEC) * ES;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (wave * 8 + RP * i) * 128), 16, 0, 0);
         }
         int dy = 0, dx = 0, ioy = 0, iox = 0;
         const char* sp; int sst, coff;
@@ -377,10 +387,12 @@ __global__ __launch_bounds__(256) void conv_igemm_dma(const ConvK a) {
                 const size_t pix = ((size_t)pn[i] * a.Hx + (yy * a.isc + ioy)) * a.Wx + (xx * a.isc + iox);
                 src = sp + (pix * sst + (size_t)coff * VEC) * ES;
             }
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + (wave * 8 + RP * i) * 128), 16, 0, 0);
         }
-        cv += 8;
-        while (cv >= a.KV) { cv -= a.KV; ++tap; }
+        if (kok) {
+            cv += 8;
+            while (cv >= a.KV) { cv -= a.KV; ++tap; }
+        }
     };
 
     f32x16_t acc[TM][TN];
@@ -394,13 +406,14 @@ __global__ __launch_bounds__(256) void conv_igemm_dma(const ConvK a) {
     const int wr = wave / WC, wc = wave % WC;
     const int frow = lane & 31, fk = lane >> 5;
 
-    issue_chunk(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue_chunk(s, s);
+    int rbuf = 0, wbuf = NS - 1;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int cur = chunk & 1;
-        if (chunk + 1 < nchunks) issue_chunk(chunk + 1, cur ^ 1);
-        const char* sA = smem + cur * BUF;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");   // this wave's part of `chunk` has landed
+        __builtin_amdgcn_s_barrier();                                          // everyone's has; buffer wbuf is free
+        issue_chunk(chunk + NS - 1, wbuf);
+        const char* sA = smem + rbuf * BUF;
         const char* sB = sA + BM * 128;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -414,9 +427,10 @@ __global__ __launch_bounds__(256) void conv_igemm_dma(const ConvK a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next chunk has landed
-        __syncthreads();                                     // everyone's has, and everyone is done reading `cur`
+        rbuf = rbuf + 1 == NS ? 0 : rbuf + 1;
+        wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the zero-page tail groups before LDS is released
     conv_epilogue<T, WR, WC, TM, TN>(a, acc, co_tile, px_tile, phase, wr, wc, frow, fk);
 }
 
@@ -456,12 +470,11 @@ __global__ __launch_bounds__(256) void conv_wgrad(const ConvK a) {
     constexpr int NMT_A = BM / VEC * 8, NMT_B = BN / VEC * 8;  // micro-tiles (VEC ch x VEC px)
     constexpr int NIT = (NMT_A + NMT_B + 255) / 256;
     static_assert(WR * WC * WK == 4, "4 waves");
-    constexpr int kStageBytes = (BM + BN) * 128 + BTS_MAX_TAP * 4;
+    constexpr int BUF = (BM + BN) * 128;
+    constexpr int kStageBytes = 2 * BUF + BTS_MAX_TAP * 4;
     constexpr int kReduceBytes = (WK - 1) * BM * BN * 4;      // cross-wave K reduction of the accumulators
     __shared__ __attribute__((aligned(16))) char smem[kStageBytes > kReduceBytes ? kStageBytes : kReduceBytes];
-    char* sA = smem;
-    char* sB = smem + BM * 128;
-    uint32_t* sTap = (uint32_t*)(smem + (BM + BN) * 128);
+    uint32_t* sTap = (uint32_t*)(smem + 2 * BUF);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int phase = blockIdx.z, split = blockIdx.y;
@@ -522,13 +535,18 @@ __global__ __launch_bounds__(256) void conv_wgrad(const ConvK a) {
     const int c_begin = split * a.chunks_per_split;
     const int c_end = min(a.nchunks, c_begin + a.chunks_per_split);
 
-    u32x4_t stage[NIT][VEC];
-    auto load_chunk = [&](int chunk) {
+    // Two register stages + two LDS buffers: the global loads of chunk c+2 are issued right after chunk c
+    // has been written to LDS, so every load has two chunk periods (MFMA + barrier) to land, and there is
+    // a single barrier per chunk (the write of chunk c+2 into buffer c&1 is ordered behind the reads of
+    // chunk c by the barrier of chunk c+1).
+    auto load_chunk = [&](int chunk, u32x4_t (&stage)[NIT][VEC]) {
+        const bool cok = chunk < c_end;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int m0 = chunk * PK + cc[it] * VEC;
             uint32_t n = 0, y = 0, x = 0;
-            if (live[it] && m0 < a.M) {
+            const bool on = cok && live[it];
+            if (on && m0 < a.M) {
                 n = fdiv(m0, a.fd_hw);
                 const uint32_t rem = m0 - n * (uint32_t)(a.Hg * a.Wg);
                 y = fdiv(rem, a.fd_w);
@@ -537,7 +555,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(const ConvK a) {
 #pragma unroll
             for (int p = 0; p < VEC; ++p) {
                 u32x4_t v = {0, 0, 0, 0};
-                if (live[it] && m0 + p < a.M) {
+                if (on && m0 + p < a.M) {
                     if (isA[it]) {
                         const size_t pix = ((size_t)n * a.Hy + (y * a.osc + pa)) * a.Wy + (x * a.osc + pb);
                         v = *(const u32x4_t*)(bptr[it] + pix * bstride[it] * ES);
@@ -554,7 +572,9 @@ __global__ __launch_bounds__(256) void conv_wgrad(const ConvK a) {
             }
         }
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](u32x4_t (&stage)[NIT][VEC], int buf) {
+        char* sA = smem + buf * BUF;
+        char* sB = sA + BM * 128;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (tid + it * 256 >= NMT_A + NMT_B) continue;
@@ -565,31 +585,36 @@ __global__ __launch_bounds__(256) void conv_wgrad(const ConvK a) {
             for (int c = 0; c < VEC; ++c) *(u32x4_t*)(base + lds_off(rg[it] * VEC + c, cc[it])) = tr[c];
         }
     };
+    auto compute = [&](int buf) {
+        const char* sA = smem + buf * BUF;
+        const char* sB = sA + BM * 128;
+#pragma unroll
+        for (int s = wk; s < 4; s += WK) {
+            u32x4_t fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4_t*)(sA + lds_off((wr * TM + i) * 32 + frow, 2 * s + fk));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *(const u32x4_t*)(sB + lds_off((wc * TN + j) * 32 + frow, 2 * s + fk));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+    };
 
-    if (c_begin < c_end) {
-        load_chunk(c_begin);
-        store_chunk();
+    u32x4_t st0[NIT][VEC], st1[NIT][VEC];
+    load_chunk(c_begin, st0);
+    load_chunk(c_begin + 1, st1);
+    for (int chunk = c_begin; chunk < c_end; chunk += 2) {
+        store_chunk(st0, 0);
         __syncthreads();
-        for (int chunk = c_begin; chunk < c_end; ++chunk) {
-            const bool more = chunk + 1 < c_end;
-            if (more) load_chunk(chunk + 1);
-#pragma unroll
-            for (int s = wk; s < 4; s += WK) {
-                u32x4_t fa[TM], fb[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4_t*)(sA + lds_off((wr * TM + i) * 32 + frow, 2 * s + fk));
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = *(const u32x4_t*)(sB + lds_off((wc * TN + j) * 32 + frow, 2 * s + fk));
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
-            }
+        load_chunk(chunk + 2, st0);
+        compute(0);
+        if (chunk + 1 < c_end) {          // block-uniform
+            store_chunk(st1, 1);
             __syncthreads();
-            if (more) {
-                store_chunk();
-                __syncthreads();
-            }
+            load_chunk(chunk + 3, st1);
+            compute(1);
         }
     }
 
@@ -756,16 +781,25 @@ static bool use_lds_dma() {
 template <typename T>
 static int launch_fwd(const ConvK& k0, hipStream_t st) {
     ConvK k = k0;
-    auto go = [&](auto kern, int BM, int BN) {
+    auto go2 = [&](auto kern, int BM, int BN, int threads) {
         k.n_co_tiles = ceil_div(k.Cout, BM);
         k.n_px_tiles = ceil_div(k.M, BN);
         dim3 grid(k.n_co_tiles * k.n_px_tiles, k.nphase);
-        hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, k);
+        hipLaunchKernelGGL(kern, grid, dim3(threads), 0, st, k);
     };
+    auto go = [&](auto kern, int BM, int BN) { go2(kern, BM, BN, 256); };
     if (use_lds_dma()) {
-        if (k.Cout > 64) go(conv_igemm_dma<T, 2, 2, 2, 2>, 128, 128);
-        else if (k.Cout > 32) go(conv_igemm_dma<T, 1, 4, 2, 1>, 64, 128);   // 2 x 24 KB LDS: 3 blocks/CU
-        else go(conv_igemm_dma<T, 1, 4, 1, 2>, 32, 256);
+        // tile / pipeline depth by problem shape (LDS: NS * (BM+BN) * 128 B):
+        //   L  128co x 256px, 8 waves, 3 stages (144 KiB, 1 WG/CU, 2 waves/SIMD)  -- wide layers with many pixel tiles
+        //   M  128co x 128px, 4 waves, 3 stages ( 96 KiB, 1 WG/CU)                 -- wide layers on small maps
+        //   S64 64co x 128px, 4 waves, 3 stages ( 72 KiB, 2 WG/CU)
+        //   S32 32co x 256px, 4 waves, 2 stages ( 72 KiB, 2 WG/CU)
+        const long px_tiles_L = (k.M + 255) / 256;
+        const long co_tiles = (k.Cout + 127) / 128;
+        if (k.Cout > 64 && px_tiles_L * co_tiles * k.nphase >= 384) go2(conv_igemm_dma<T, 2, 4, 2, 2, 3>, 128, 256, 512);
+        else if (k.Cout > 64) go2(conv_igemm_dma<T, 2, 2, 2, 2, 3>, 128, 128, 256);
+        else if (k.Cout > 32) go2(conv_igemm_dma<T, 1, 4, 2, 1, 3>, 64, 128, 256);
+        else go2(conv_igemm_dma<T, 1, 4, 1, 2, 2>, 32, 256, 256);
     } else {
         if (k.Cout > 64) go(conv_igemm<T, 2, 2, 2, 2>, 128, 128);
         else if (k.Cout > 32) go(conv_igemm<T, 1, 4, 2, 2>, 64, 256);
