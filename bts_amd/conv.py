@@ -51,10 +51,7 @@ def _dn(dtype):
 
 
 def _tile(cout, M=0, nphase=1):      # mirrors launch_fwd() in csrc/conv_igemm.hip (LDS-DMA variants)
-    if cout > 64:
-        big = ((M + 255) // 256) * ((cout + 127) // 128) * nphase >= 384
-        return "128x256x3" if big else "128x128x3"
-    return "64x128x3" if cout > 32 else "32x256x2"
+    return "128x128" if cout > 64 else ("64x128" if cout > 32 else "32x256")
 
 
 def _wtile(cout):     # mirrors launch_wgrad()

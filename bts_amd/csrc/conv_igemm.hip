@@ -43,6 +43,8 @@ struct ConvK {
     int Hx, Wx, isc;
     int T, nphase, Ttot;
     uint32_t taps[BTS_MAX_TAP];  // dy:8 | dx:8 | ioy:4 | iox:4
+    int tapoff[BTS_MAX_TAP];     // input-pixel offset of the tap: (dy*isc+ioy)*Wx + dx*isc + iox
+    uint32_t seg_sb[BTS_MAX_SEG];  // pixel stride of each segment in BYTES
     const char* w;
     int Cout, Ktot;
     char* y;
@@ -294,6 +296,25 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK a) {
     conv_epilogue<T, WR, WC, TM, TN>(a, acc, co_tile, px_tile, phase, wr, wc, frow, fk);
 }
 
+// segment lookup for the strength-reduced address path: index, base pointer, byte stride, channel byte offset
+__device__ __forceinline__ void pick_seg_b(const ConvK& a, int cv, int vec_bytes, int& seg, const char*& sp, uint32_t& sb,
+                                           uint32_t& coffB) {
+    seg = 0;
+    sp = a.seg_ptr[0];
+    sb = a.seg_sb[0];
+    int coff = cv;
+#pragma unroll
+    for (int s = 1; s < BTS_MAX_SEG; ++s) {
+        if (s < a.nseg && cv >= a.seg_cum[s]) {
+            seg = s;
+            sp = a.seg_ptr[s];
+            sb = a.seg_sb[s];
+            coff = cv - a.seg_cum[s];
+        }
+    }
+    coffB = (uint32_t)(coff * vec_bytes);
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel, LDS-DMA staging (global_load_lds_dwordx4, 16 B per lane)
 //
@@ -324,42 +345,52 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
     constexpr int BUF = (BM + BN) * 128;
     static_assert(BM % RP == 0 && BN % RP == 0, "tile rows must be a multiple of the DMA pass");
     static_assert((NS - 2) * G <= 63, "vmcnt range");
-    __shared__ __attribute__((aligned(16))) char smem[NS * BUF + BTS_MAX_TAP * 4];
+    __shared__ __attribute__((aligned(16))) char smem[NS * BUF + BTS_MAX_TAP * 8];
     uint32_t* sTap = (uint32_t*)(smem + NS * BUF);
+    int* sTapOff = (int*)(smem + NS * BUF + BTS_MAX_TAP * 4);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int phase = blockIdx.y;
     const int L = remap_xcd(blockIdx.x, a.n_px_tiles * a.n_co_tiles);
     const int co_tile = L % a.n_co_tiles, px_tile = L / a.n_co_tiles;
-    if (tid < BTS_MAX_TAP) sTap[tid] = a.taps[tid];
+    if (tid < BTS_MAX_TAP) { sTap[tid] = a.taps[tid]; sTapOff[tid] = a.tapoff[tid]; }
 
     const int pc = tid & 7, srow = tid >> 3;          // physical chunk / row this lane's DMA lands in
     const int vec = pc ^ ((srow >> 1) & 7);           // logical K chunk it must fetch (rows differ by RP*i: same swizzle)
-    int py[RB], px[RB], pn[RB];
+    // Per-row invariants.  All address arithmetic in the K loop is adds on 32-bit byte offsets: integer
+    // multiplies are quarter-rate VALU ops and were the limiter of the first version of this kernel.
+    int py[RB], px[RB];
+    uint32_t rowpix[RB], rowoff[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const int m = px_tile * BN + srow + RP * i;
+        rowoff[i] = 0;
         if (m < a.M) {
             const uint32_t n = fdiv(m, a.fd_hw);
             const uint32_t rem = m - n * (uint32_t)(a.Hg * a.Wg);
             const uint32_t y = fdiv(rem, a.fd_w);
+            const uint32_t x = rem - y * a.Wg;
             py[i] = (int)y;
-            px[i] = (int)(rem - y * a.Wg);
-            pn[i] = (int)n;
+            px[i] = (int)x;
+            rowpix[i] = n * (uint32_t)(a.Hx * a.Wx) + (uint32_t)a.isc * (y * a.Wx + x);
         } else {
-            py[i] = px[i] = 0;
-            pn[i] = -1;
+            py[i] = px[i] = -100000;                   // fails every bounds test
+            rowpix[i] = 0;
         }
     }
     const int TKV = a.T * a.KV;
     const int nchunks = (TKV + 7) >> 3;
-    const size_t w_phase_off = (size_t)phase * a.T * a.Ktot;
-    const size_t w_row = (size_t)a.Ttot * a.Ktot;
     const char* zero = (const char*)kZeroPage;
+    const char* wrow[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int co = co_tile * BM + srow + RP * i;
+        wrow[i] = co < a.Cout ? a.w + ((size_t)co * a.Ttot + (size_t)phase * a.T) * a.Ktot * ES : nullptr;
+    }
 
-    int tap = 0, cv = vec;
+    int tap = 0, cv = vec, curseg = -1;
     while (cv >= a.KV) { cv -= a.KV; ++tap; }
-    __syncthreads();  // tap table visible
+    __syncthreads();  // tap tables visible
 
     // always issues exactly G DMA instructions per thread (chunks past the end fetch the zero page),
     // so the vmcnt arithmetic below is uniform
@@ -368,25 +399,29 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
         char* sB = sA + BM * 128;
         const int kv = chunk * 8 + vec;
         const bool kok = kv < TKV;
+        const uint32_t kB = (uint32_t)kv * (VEC * ES);
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int co = co_tile * BM + srow + RP * i;
-            const char* src = zero;
-            if (kok && co < a.Cout) src = a.w + ((size_t)co * w_row + w_phase_off + (size_t)kv * VEC) * ES;
+            const char* src = (kok && wrow[i]) ? wrow[i] + kB : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (wave * 8 + RP * i) * 128), 16, 0, 0);
         }
-        int dy = 0, dx = 0, ioy = 0, iox = 0;
-        const char* sp; int sst, coff;
-        pick_seg(a, cv, sp, sst, coff);
-        if (kok) decode_tap(sTap[phase * a.T + tap], dy, dx, ioy, iox);
+        int dy = 0, dx = 0, ioy = 0, iox = 0, toff = 0;
+        int seg; const char* sp; uint32_t sb, coffB;
+        pick_seg_b(a, cv, VEC * ES, seg, sp, sb, coffB);
+        if (kok) {
+            decode_tap(sTap[phase * a.T + tap], dy, dx, ioy, iox);
+            toff = sTapOff[phase * a.T + tap];
+        }
+        if (seg != curseg) {                           // rare: the lane crossed into another input segment
+            curseg = seg;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) rowoff[i] = rowpix[i] * sb;
+        }
+        const char* base = sp + (long)coffB + (long)(toff * (int)sb);
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int yy = py[i] + dy, xx = px[i] + dx;
-            const char* src = zero;
-            if (kok && pn[i] >= 0 && (unsigned)yy < (unsigned)a.Hg && (unsigned)xx < (unsigned)a.Wg) {
-                const size_t pix = ((size_t)pn[i] * a.Hx + (yy * a.isc + ioy)) * a.Wx + (xx * a.isc + iox);
-                src = sp + (pix * sst + (size_t)coff * VEC) * ES;
-            }
+            const bool ok = kok && (unsigned)(py[i] + dy) < (unsigned)a.Hg && (unsigned)(px[i] + dx) < (unsigned)a.Wg;
+            const char* src = ok ? base + rowoff[i] : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + (wave * 8 + RP * i) * 128), 16, 0, 0);
         }
         if (kok) {
@@ -539,36 +574,57 @@ __global__ __launch_bounds__(256) void conv_wgrad(const ConvK a) {
     // has been written to LDS, so every load has two chunk periods (MFMA + barrier) to land, and there is
     // a single barrier per chunk (the write of chunk c+2 into buffer c&1 is ordered behind the reads of
     // chunk c by the barrier of chunk c+1).
+    // per-micro-tile byte steps between consecutive conv-domain pixels (x+1 / next row / next image), so the
+    // K loop needs multiplies only for the first pixel of a micro-tile (integer multiplies are quarter rate)
+    uint32_t sB_[NIT], dX[NIT], dRow[NIT], dImg[NIT];
+    int toffs[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const uint32_t S = (uint32_t)bstride[it] * ES;
+        sB_[it] = S;
+        if (isA[it]) {
+            dX[it] = (uint32_t)a.osc * S;
+            dRow[it] = (uint32_t)(a.osc * a.Wy - a.osc * (a.Wg - 1)) * S;
+            dImg[it] = (uint32_t)(a.Hy * a.Wy - ((a.Hg - 1) * a.osc * a.Wy + (a.Wg - 1) * a.osc)) * S;
+            toffs[it] = pa * a.Wy + pb;
+        } else {
+            dX[it] = (uint32_t)a.isc * S;
+            dRow[it] = (uint32_t)(a.isc * a.Wx - a.isc * (a.Wg - 1)) * S;
+            dImg[it] = (uint32_t)(a.Hx * a.Wx - a.isc * ((a.Hg - 1) * a.Wx + (a.Wg - 1))) * S;
+            toffs[it] = (bdy[it] * a.isc + bioy[it]) * a.Wx + bdx[it] * a.isc + biox[it];
+        }
+    }
     auto load_chunk = [&](int chunk, u32x4_t (&stage)[NIT][VEC]) {
         const bool cok = chunk < c_end;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int m0 = chunk * PK + cc[it] * VEC;
-            uint32_t n = 0, y = 0, x = 0;
-            const bool on = cok && live[it];
-            if (on && m0 < a.M) {
+            const bool on = cok && live[it] && m0 < a.M;
+            uint32_t n = 0, y = 0, x = 0, off = 0;
+            if (on) {
                 n = fdiv(m0, a.fd_hw);
                 const uint32_t rem = m0 - n * (uint32_t)(a.Hg * a.Wg);
                 y = fdiv(rem, a.fd_w);
                 x = rem - y * a.Wg;
+                const uint32_t pix = isA[it] ? (n * (uint32_t)a.Hy + y * a.osc) * a.Wy + x * a.osc
+                                             : n * (uint32_t)(a.Hx * a.Wx) + (uint32_t)a.isc * (y * a.Wx + x);
+                off = (pix + (uint32_t)toffs[it]) * sB_[it];
             }
+            const int dy = isA[it] ? 0 : bdy[it], dx = isA[it] ? 0 : bdx[it];
 #pragma unroll
             for (int p = 0; p < VEC; ++p) {
                 u32x4_t v = {0, 0, 0, 0};
-                if (on && m0 + p < a.M) {
-                    if (isA[it]) {
-                        const size_t pix = ((size_t)n * a.Hy + (y * a.osc + pa)) * a.Wy + (x * a.osc + pb);
-                        v = *(const u32x4_t*)(bptr[it] + pix * bstride[it] * ES);
-                    } else {
-                        const int yy = (int)y + bdy[it], xx = (int)x + bdx[it];
-                        if ((unsigned)yy < (unsigned)a.Hg && (unsigned)xx < (unsigned)a.Wg) {
-                            const size_t pix = ((size_t)n * a.Hx + (yy * a.isc + bioy[it])) * a.Wx + (xx * a.isc + biox[it]);
-                            v = *(const u32x4_t*)(bptr[it] + pix * bstride[it] * ES);
-                        }
-                    }
-                }
+                const bool ok = on && m0 + p < a.M && (unsigned)((int)y + dy) < (unsigned)a.Hg &&
+                                (unsigned)((int)x + dx) < (unsigned)a.Wg;
+                if (ok) v = *(const u32x4_t*)(bptr[it] + off);
                 stage[it][p] = v;
-                if (++x == (uint32_t)a.Wg) { x = 0; if (++y == (uint32_t)a.Hg) { y = 0; ++n; } }
+                if (++x == (uint32_t)a.Wg) {
+                    x = 0;
+                    if (++y == (uint32_t)a.Hg) { y = 0; off += dImg[it]; }
+                    else off += dRow[it];
+                } else {
+                    off += dX[it];
+                }
             }
         }
     };
@@ -763,6 +819,14 @@ static int fill_common(const bts_conv_desc_t* d, ConvK& k) {
                 ((uint32_t)d->ioy[t] << 16) | ((uint32_t)d->iox[t] << 20);
         }
         k.taps[t] = v;
+        k.tapoff[t] = t < k.Ttot ? (d->dy[t] * d->isc + d->ioy[t]) * d->Wx + d->dx[t] * d->isc + d->iox[t] : 0;
+    }
+    {   // kernels use 32-bit byte offsets inside a tensor
+        const long es = d->dtype == BTS_F32 ? 4 : 2;
+        for (int s = 0; s < d->nseg; ++s) {
+            k.seg_sb[s] = (uint32_t)(d->seg[s].stride * es);
+            if ((long)d->N * d->Hx * d->Wx * d->seg[s].stride * es >= (1l << 32)) return BTS_ERR_UNSUPPORTED;
+        }
     }
     k.Cout = d->Cout;
     k.Hy = d->Hy; k.Wy = d->Wy; k.osc = d->osc;
@@ -794,11 +858,14 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
         //   M  128co x 128px, 4 waves, 3 stages ( 96 KiB, 1 WG/CU)                 -- wide layers on small maps
         //   S64 64co x 128px, 4 waves, 3 stages ( 72 KiB, 2 WG/CU)
         //   S32 32co x 256px, 4 waves, 2 stages ( 72 KiB, 2 WG/CU)
-        const long px_tiles_L = (k.M + 255) / 256;
-        const long co_tiles = (k.Cout + 127) / 128;
-        if (k.Cout > 64 && px_tiles_L * co_tiles * k.nphase >= 384) go2(conv_igemm_dma<T, 2, 4, 2, 2, 3>, 128, 256, 512);
-        else if (k.Cout > 64) go2(conv_igemm_dma<T, 2, 2, 2, 2, 3>, 128, 128, 256);
-        else if (k.Cout > 32) go2(conv_igemm_dma<T, 1, 4, 2, 1, 3>, 64, 128, 256);
+        static const char big = [] { const char* e = getenv("BTS_CONV_BIG"); return e ? e[0] : 'a'; }();   // A/B knob
+        if (k.Cout > 64) {
+            if (big == 'b') go2(conv_igemm_dma<T, 2, 2, 2, 2, 3>, 128, 128, 256);
+            else if (big == 'c') go2(conv_igemm_dma<T, 2, 4, 2, 2, 3>, 128, 256, 512);
+            else if (big == 'd') go2(conv_igemm_dma<T, 2, 4, 2, 2, 2>, 128, 256, 512);
+            else go2(conv_igemm_dma<T, 2, 2, 2, 2, 2>, 128, 128, 256);
+        }
+        else if (k.Cout > 32) go2(conv_igemm_dma<T, 1, 4, 2, 1, 2>, 64, 128, 256);
         else go2(conv_igemm_dma<T, 1, 4, 1, 2, 2>, 32, 256, 256);
     } else {
         if (k.Cout > 64) go(conv_igemm<T, 2, 2, 2, 2>, 128, 128);
