@@ -854,11 +854,12 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
     auto go = [&](auto kern, int BM, int BN) { go2(kern, BM, BN, 256); };
     if (use_lds_dma()) {
         // tile / pipeline depth by problem shape (LDS: NS * (BM+BN) * 128 B):
-        //   L  128co x 256px, 8 waves, 3 stages (144 KiB, 1 WG/CU, 2 waves/SIMD)  -- wide layers with many pixel tiles
-        //   M  128co x 128px, 4 waves, 3 stages ( 96 KiB, 1 WG/CU)                 -- wide layers on small maps
-        //   S64 64co x 128px, 4 waves, 3 stages ( 72 KiB, 2 WG/CU)
-        //   S32 32co x 256px, 4 waves, 2 stages ( 72 KiB, 2 WG/CU)
-        static const char big = [] { const char* e = getenv("BTS_CONV_BIG"); return e ? e[0] : 'a'; }();   // A/B knob
+        //   d  128co x 256px, 8 waves, 2 stages ( 96 KiB, 1 WG/CU = 2 waves/SIMD)  [r1: 594-644 TF on conv5/daspp_conv]
+        //   a  128co x 128px, 4 waves, 2 stages ( 64 KiB, 2 WG/CU)                  [r1: 553-592 TF]
+        //   b  128co x 128px, 4 waves, 3 stages ( 96 KiB, 1 WG/CU = 1 wave/SIMD)   [r1: 339-368 TF: too few waves]
+        //   c  128co x 256px, 8 waves, 3 stages (144 KiB)                           [r1: = d; depth is not the limiter]
+        //   64co x 128px and 32co x 256px, 4 waves, 2 stages for narrow layers
+        static const char big = [] { const char* e = getenv("BTS_CONV_BIG"); return e ? e[0] : 'd'; }();   // A/B knob (d = default)
         if (k.Cout > 64) {
             if (big == 'b') go2(conv_igemm_dma<T, 2, 2, 2, 2, 3>, 128, 128, 256);
             else if (big == 'c') go2(conv_igemm_dma<T, 2, 4, 2, 2, 3>, 128, 256, 512);

@@ -103,7 +103,8 @@ __device__ __forceinline__ Plane plane_from_raw(float r0, float r1, float r2, fl
     p.s0 = act_sigmoid(r0); p.s1 = act_sigmoid(r1); p.s2 = act_sigmoid(r2);
     const float theta = __fdiv_rn(__fmul_rn(p.s0, 3.14159274101257324f), 3.0f);   // sigmoid * math.pi / 3 (bts.py:113)
     const float phi = __fmul_rn(__fmul_rn(p.s1, 3.14159274101257324f), 2.0f);     // sigmoid * math.pi * 2 (bts.py:114)
-    p.st = sinf(theta); p.ct = cosf(theta); p.sp = sinf(phi); p.cp = cosf(phi);
+    sincosf(theta, &p.st, &p.ct);
+    sincosf(phi, &p.sp, &p.cp);
     p.m1 = __fmul_rn(p.st, p.cp); p.m2 = __fmul_rn(p.st, p.sp); p.m3 = p.ct;     // bts.py:116-118
     const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(p.m1, p.m1), __fmul_rn(p.m2, p.m2)), __fmul_rn(p.m3, p.m3)));
     const float d = fmaxf(nrm, 1e-12f);                                           // F.normalize eps (bts.py:224)
@@ -113,34 +114,40 @@ __device__ __forceinline__ Plane plane_from_raw(float r0, float r1, float r2, fl
     return p;
 }
 
-// forward: one thread per (cell, patch row) -- K x more threads than cells so that even the k = 8 head
-// (B*h*w = 53 k cells at 352x1216, batch 8) fills all 256 CUs; consecutive lanes = consecutive cells of
-// the same output row => each wave store covers 64*K consecutive floats.  The plane is re-derived per
-// row (K x redundant transcendental work, invisible next to the HBM time).
-template <int K>
+// forward: RPT patch rows per thread.  k = 8 uses one thread per (cell, row) -- 8x more threads than cells,
+// so even B*h*w = 53 k cells (352x1216, batch 8) fill all 256 CUs; k = 4 / 2 use one thread per cell
+// (all k rows), which keeps the transcendental work (sigmoid x3, sincos x2, normalise) at once per cell --
+// with k*k <= 16 outputs per cell the kernel would otherwise be VALU-bound, not HBM-bound.  Consecutive lanes
+// = consecutive cells of the same output row => each wave store covers 64*K consecutive floats.
+template <int K, int RPT>
 __global__ __launch_bounds__(256) void lpg_head_fwd_kernel(const float* __restrict__ raw, int raw_stride,
                                                            float* __restrict__ depth, float* __restrict__ eq_out,
                                                            int cells, int h, int w, float max_depth) {
+    constexpr int NR = K / RPT;                             // threads per cell
     const long t = blockIdx.x * 256l + threadIdx.x;
-    if (t >= (long)cells * K) return;
+    if (t >= (long)cells * NR) return;
     const int j = (int)(t % w);
     const long q = t / w;
-    const int r = (int)(q % K);
-    const long bi = q / K;                                  // b*h + i
+    const int r0 = (int)(q % NR) * RPT;
+    const long bi = q / NR;                                 // b*h + i
     const long cell = bi * w + j;
     const float* rp = raw + (size_t)cell * raw_stride;
     const Plane p = plane_from_raw(rp[0], rp[1], rp[2], max_depth);
-    if (eq_out && r == 0) *(f32x4_t*)(eq_out + (size_t)cell * 4) = f32x4_t{p.n1, p.n2, p.n3, p.n4};
-    float* out = depth + ((size_t)bi * K + r) * ((size_t)w * K) + (size_t)j * K;
-    const float v = lpg_offset(r, K);
-    float o[K];
+    if (eq_out && r0 == 0) *(f32x4_t*)(eq_out + (size_t)cell * 4) = f32x4_t{p.n1, p.n2, p.n3, p.n4};
 #pragma unroll
-    for (int c = 0; c < K; ++c) o[c] = lpg_eval(p.n1, p.n2, p.n3, p.n4, lpg_offset(c, K), v, max_depth);
-    if (K >= 4) {
+    for (int rr = 0; rr < RPT; ++rr) {
+        const int r = r0 + rr;
+        float* out = depth + ((size_t)bi * K + r) * ((size_t)w * K) + (size_t)j * K;
+        const float v = lpg_offset(r, K);
+        float o[K];
 #pragma unroll
-        for (int c = 0; c < K; c += 4) *(f32x4_t*)(out + c) = f32x4_t{o[c], o[c + 1], o[c + 2], o[c + 3]};
-    } else {
-        *(float2*)out = make_float2(o[0], o[1]);
+        for (int c = 0; c < K; ++c) o[c] = lpg_eval(p.n1, p.n2, p.n3, p.n4, lpg_offset(c, K), v, max_depth);
+        if (K >= 4) {
+#pragma unroll
+            for (int c = 0; c < K; c += 4) *(f32x4_t*)(out + c) = f32x4_t{o[c], o[c + 1], o[c + 2], o[c + 3]};
+        } else {
+            *(float2*)out = make_float2(o[0], o[1]);
+        }
     }
 }
 
@@ -385,11 +392,11 @@ extern "C" int bts_lpg_head_fwd(const float* raw, int raw_stride, float* depth, 
     BTS_CHECK_ARG(((uintptr_t)depth & 15) == 0 && ((uintptr_t)plane_eq & 15) == 0);
     const int cells = B * h * w;
     hipStream_t st = (hipStream_t)stream;
-    dim3 g(ceil_div((long)cells * k, 256)), b(256);
+    dim3 b(256);
     switch (k) {
-        case 8: hipLaunchKernelGGL(lpg_head_fwd_kernel<8>, g, b, 0, st, raw, raw_stride, depth, plane_eq, cells, h, w, max_depth); break;
-        case 4: hipLaunchKernelGGL(lpg_head_fwd_kernel<4>, g, b, 0, st, raw, raw_stride, depth, plane_eq, cells, h, w, max_depth); break;
-        default: hipLaunchKernelGGL(lpg_head_fwd_kernel<2>, g, b, 0, st, raw, raw_stride, depth, plane_eq, cells, h, w, max_depth); break;
+        case 8: hipLaunchKernelGGL((lpg_head_fwd_kernel<8, 1>), dim3(ceil_div((long)cells * 8, 256)), b, 0, st, raw, raw_stride, depth, plane_eq, cells, h, w, max_depth); break;
+        case 4: hipLaunchKernelGGL((lpg_head_fwd_kernel<4, 4>), dim3(ceil_div(cells, 256)), b, 0, st, raw, raw_stride, depth, plane_eq, cells, h, w, max_depth); break;
+        default: hipLaunchKernelGGL((lpg_head_fwd_kernel<2, 2>), dim3(ceil_div(cells, 256)), b, 0, st, raw, raw_stride, depth, plane_eq, cells, h, w, max_depth); break;
     }
     BTS_LAUNCH_CHECK();
     return BTS_OK;
