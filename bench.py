@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--graph", type=int, default=1, help="capture the train step in a hipGraph (N=1 only; falls back to eager)")
     ap.add_argument("--cudnn-benchmark", type=int, default=0)
+    ap.add_argument("--optimizer", default="bts", choices=["bts", "torch"], help="bts = fused HIP AdamW (bts_adamw_step)")
     return ap.parse_args()
 
 
@@ -171,9 +172,14 @@ def main():
     use_graph = bool(args.graph) and world == 1
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
     lr_t = torch.tensor(1e-4, device=dev)      # capturable optimizers read lr from a device tensor
-    opt = torch.optim.AdamW([{"params": [p for p in model.encoder.parameters() if p.requires_grad], "weight_decay": 1e-2},
-                             {"params": list(model.decoder.parameters()), "weight_decay": 0.0}],
-                            lr=lr_t if use_graph else 1e-4, eps=1e-3, fused=True, capturable=use_graph)
+    groups = [{"params": [p for p in model.encoder.parameters() if p.requires_grad], "weight_decay": 1e-2},
+              {"params": list(model.decoder.parameters()), "weight_decay": 0.0}]       # bts_main.py:371-373
+    own_opt = args.optimizer == "bts"
+    if own_opt:
+        from bts_amd.optim import FusedAdamW
+        opt = FusedAdamW(groups, lr=1e-4, eps=1e-3)
+    else:
+        opt = torch.optim.AdamW(groups, lr=lr_t if use_graph else 1e-4, eps=1e-3, fused=True, capturable=use_graph)
     crit = silog_loss(0.85)
     image, focal, gt = make_batch(args, dev, 1234 + rank)
     if args.channels_last:
@@ -186,21 +192,29 @@ def main():
         return (1e-4 - 1e-5) * (1 - gstep[0] / total_steps) ** 0.9 + 1e-5     # bts_main.py:456-458
 
     def step_body():
-        opt.zero_grad(set_to_none=True)
+        opt.zero_grad(set_to_none=not own_opt)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
             outs = net(image, focal)
         loss = crit(outs[4], gt, mask)
         loss.backward()
-        opt.step()
+        if own_opt:
+            opt.step(prepared=True)
+        else:
+            opt.step()
         return loss
 
-    def step_eager():
+    def set_lr():
         lr = poly_lr()
-        for g in opt.param_groups:
-            if use_graph:
-                g["lr"].fill_(lr)
-            else:
+        if own_opt:
+            opt.prepare_step(lrs=[lr, lr])          # device-resident {lr, bias corrections}: outside any graph
+        elif use_graph:
+            lr_t.fill_(lr)
+        else:
+            for g in opt.param_groups:
                 g["lr"] = lr
+
+    def step_eager():
+        set_lr()
         loss = step_body()
         gstep[0] += 1
         return loss
@@ -228,7 +242,7 @@ def main():
     def step():
         if graph is None:
             return step_eager()
-        lr_t.fill_(poly_lr())
+        set_lr()
         graph.replay()
         gstep[0] += 1
         return static_loss
@@ -275,7 +289,7 @@ def main():
             "config": {"workload": "%s train step (fwd+silog+bwd+AdamW), %dx%d, %d img/GPU, kitti focal scaling" %
                        (args.encoder, args.height, args.width, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "encoder": "stock PyTorch-ROCm (%s autocast)" % args.dtype, "decoder": "HIP kernels via libbts_amd.so", "launch": graph_note,
+                       "encoder": "stock PyTorch-ROCm (%s autocast)" % args.dtype, "decoder": "HIP kernels via libbts_amd.so", "launch": graph_note, "optimizer": "bts_adamw_step (fused HIP)" if own_opt else "torch.optim.AdamW(fused)",
                        "final_loss": round(final_loss, 5)},
         }
         if roof is not None:

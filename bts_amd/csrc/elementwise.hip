@@ -348,7 +348,8 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restric
 __global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ params, float* const* __restrict__ grads,
                                                     float* const* __restrict__ m1, float* const* __restrict__ m2,
                                                     const long* __restrict__ sizes, float lr, float b1, float b2, float eps,
-                                                    float wd, float bc1, float bc2) {
+                                                    float wd, float bc1, float bc2, const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; }   // device-resident schedule (hipGraph replay)
     const int t = blockIdx.y;
     const long n = sizes[t];
     float* p = params[t]; const float* g = grads[t]; float* a = m1[t]; float* b = m2[t];
@@ -556,13 +557,13 @@ extern "C" int bts_nhwc_to_nchw(const void* src, int src_dtype, int src_stride, 
 
 extern "C" int bts_adamw_step(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                               const long* sizes, int n_tensors, long max_size, float lr, float beta1, float beta2, float eps,
-                              float weight_decay, float bias_c1, float bias_c2, bts_stream_t stream) {
+                              float weight_decay, float bias_c1, float bias_c2, const float* dev_hyper, bts_stream_t stream) {
     BTS_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && sizes && n_tensors > 0 && max_size > 0);
     long bx = (max_size + 256 * 8 - 1) / (256 * 8);
     if (bx > 512) bx = 512;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, params, grads,
-                       exp_avg, exp_avg_sq, sizes, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2);
+                       exp_avg, exp_avg_sq, sizes, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2, dev_hyper);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }

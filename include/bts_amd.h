@@ -223,10 +223,13 @@ int bts_add_to(const void* x, int x_dtype, int x_stride, void* y, int y_dtype, i
                int accumulate, bts_stream_t stream);
 
 /* Fused multi-tensor AdamW step (torch.optim.AdamW semantics, bts_main.py:371-373, 456-460) over a
- * flat list of f32 tensors: ptr arrays live on the DEVICE. */
+ * flat list of f32 tensors: the pointer arrays and `sizes` live on the DEVICE.  bias_c1/2 = 1 - beta^t.
+ * If dev_hyper != NULL, {lr, bias_c1, bias_c2} are read from dev_hyper[0..2] on the device instead of the
+ * scalar arguments, so a captured hipGraph can be replayed with a per-step schedule. */
 int bts_adamw_step(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                    const long* sizes, int n_tensors, long max_size, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, float bias_c1, float bias_c2, bts_stream_t stream);
+                   float eps, float weight_decay, float bias_c1, float bias_c2, const float* dev_hyper,
+                   bts_stream_t stream);
 
 #ifdef __cplusplus
 }

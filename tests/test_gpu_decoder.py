@@ -171,3 +171,36 @@ def test_full_model_vs_oracle_train_step():
     g_dev = dict(model.encoder.named_parameters())["base_model.conv0.weight"].grad
     g_cpu = dict(enc_cpu.named_parameters())["base_model.conv0.weight"].grad
     assert rel(g_dev, g_cpu) < 5e-3
+
+
+def test_fused_adamw_matches_torch_adamw():
+    """bts_amd.optim.FusedAdamW == torch.optim.AdamW (values and state-dict layout) over 3 steps, 2 groups."""
+    from bts_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    ws = [torch.randn(64, 33, device=DEV), torch.randn(7, device=DEV), torch.randn(5, 3, 3, 3, device=DEV)]
+    a = [w.clone().requires_grad_(True) for w in ws]
+    b = [w.clone().requires_grad_(True) for w in ws]
+    oa = FusedAdamW([{"params": a[:2], "weight_decay": 1e-2}, {"params": a[2:], "weight_decay": 0.0}], lr=1e-3, eps=1e-3)
+    ob = torch.optim.AdamW([{"params": b[:2], "weight_decay": 1e-2}, {"params": b[2:], "weight_decay": 0.0}], lr=1e-3, eps=1e-3)
+    for it in range(3):
+        gs = [torch.randn_like(w) for w in ws]
+        for p, q, g in zip(a, b, gs):
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            q.grad = g.clone()
+        lr = 1e-3 * (1 - it / 10) ** 0.9
+        for grp in ob.param_groups:
+            grp["lr"] = lr
+        oa.prepare_step(lrs=[lr, lr])
+        oa.step(prepared=True)
+        ob.step()
+    for p, q in zip(a, b):
+        assert rel(p, q) < 1e-6
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["state"].keys() == sb["state"].keys()
+    for k in sa["state"]:
+        assert set(sa["state"][k].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+        assert rel(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"]) < 1e-6
+    ob.load_state_dict(sa)          # state written by one loads in the other
