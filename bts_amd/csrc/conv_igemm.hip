@@ -392,19 +392,17 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
     while (cv >= a.KV) { cv -= a.KV; ++tap; }
     __syncthreads();  // tap tables visible
 
-    // always issues exactly G DMA instructions per thread (chunks past the end fetch the zero page),
-    // so the vmcnt arithmetic below is uniform
-    auto issue_chunk = [&](int chunk, int buf) {
-        char* sA = smem + buf * BUF;
-        char* sB = sA + BM * 128;
+    // Address generation (prep) and DMA issue (fire) are split so that the VALU work of chunk c+NS-1 runs
+    // while this wave would otherwise sit in s_waitcnt/s_barrier.  fire always issues exactly G DMA
+    // instructions per thread (chunks past the end fetch the zero page): the vmcnt arithmetic is uniform.
+    const char* srcA[RA];
+    const char* srcB[RB];
+    auto prep_chunk = [&](int chunk) {
         const int kv = chunk * 8 + vec;
         const bool kok = kv < TKV;
         const uint32_t kB = (uint32_t)kv * (VEC * ES);
 #pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const char* src = (kok && wrow[i]) ? wrow[i] + kB : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + (wave * 8 + RP * i) * 128), 16, 0, 0);
-        }
+        for (int i = 0; i < RA; ++i) srcA[i] = (kok && wrow[i]) ? wrow[i] + kB : zero;
         int dy = 0, dx = 0, ioy = 0, iox = 0, toff = 0;
         int seg; const char* sp; uint32_t sb, coffB;
         pick_seg_b(a, cv, VEC * ES, seg, sp, sb, coffB);
@@ -421,13 +419,22 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const bool ok = kok && (unsigned)(py[i] + dy) < (unsigned)a.Hg && (unsigned)(px[i] + dx) < (unsigned)a.Wg;
-            const char* src = ok ? base + rowoff[i] : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + (wave * 8 + RP * i) * 128), 16, 0, 0);
+            srcB[i] = ok ? base + rowoff[i] : zero;
         }
         if (kok) {
             cv += 8;
             while (cv >= a.KV) { cv -= a.KV; ++tap; }
         }
+    };
+    auto fire_chunk = [&](int buf) {
+        char* sA = smem + buf * BUF;
+        char* sB = sA + BM * 128;
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)srcA[i], (lptr_t)(sA + (wave * 8 + RP * i) * 128), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)srcB[i], (lptr_t)(sB + (wave * 8 + RP * i) * 128), 16, 0, 0);
     };
 
     f32x16_t acc[TM][TN];
@@ -440,27 +447,43 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
 
     const int wr = wave / WC, wc = wave % WC;
     const int frow = lane & 31, fk = lane >> 5;
+    // per-lane LDS fragment offsets are chunk-invariant
+    int offA[TM], offB[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) offA[i] = ((wr * TM + i) * 32 + frow) * 128;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) offB[j] = BM * 128 + ((wc * TN + j) * 32 + frow) * 128;
+    const int swz = (frow >> 1) & 7;                  // (row>>1)&7 with row = 32*t + frow
 
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue_chunk(s, s);
+    for (int s = 0; s < NS - 1; ++s) { prep_chunk(s); fire_chunk(s); }
     int rbuf = 0, wbuf = NS - 1;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
+        prep_chunk(chunk + NS - 1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");   // this wave's part of `chunk` has landed
         __builtin_amdgcn_s_barrier();                                          // everyone's has; buffer wbuf is free
-        issue_chunk(chunk + NS - 1, wbuf);
-        const char* sA = smem + rbuf * BUF;
-        const char* sB = sA + BM * 128;
+        const char* sT = smem + rbuf * BUF;
+        u32x4_t fa[2][TM], fb[2][TN];
+        // k-step 0 fragments first (their LDS latency overlaps the DMA issue), then one k-step of read-ahead
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = *(const u32x4_t*)(sT + offA[i] + (((0 + fk) ^ swz) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = *(const u32x4_t*)(sT + offB[j] + (((0 + fk) ^ swz) << 4));
+        fire_chunk(wbuf);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            u32x4_t fa[TM], fb[TN];
+            if (s < 3) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4_t*)(sA + lds_off((wr * TM + i) * 32 + frow, 2 * s + fk));
+                for (int i = 0; i < TM; ++i) fa[(s + 1) & 1][i] = *(const u32x4_t*)(sT + offA[i] + (((2 * (s + 1) + fk) ^ swz) << 4));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *(const u32x4_t*)(sB + lds_off((wc * TN + j) * 32 + frow, 2 * s + fk));
+                for (int j = 0; j < TN; ++j) fb[(s + 1) & 1][j] = *(const u32x4_t*)(sT + offB[j] + (((2 * (s + 1) + fk) ^ swz) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the read-ahead ABOVE this k-step's MFMAs (hipcc sinks it otherwise)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) Mma<T>::run(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         rbuf = rbuf + 1 == NS ? 0 : rbuf + 1;
         wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;

@@ -38,7 +38,7 @@ def lpg(plane_eq, k):
     """
     B, _, h, w = plane_eq.shape
     dt = plane_eq.dtype
-    off = (torch.arange(k, dtype=dt) - (k - 1) * 0.5) / k          # [k]
+    off = (torch.arange(k, dtype=dt, device=plane_eq.device) - (k - 1) * 0.5) / k          # [k]
     u = off.repeat(w).view(1, 1, w * k)                            # varies with column
     v = off.repeat(h).view(1, h * k, 1)                            # varies with row
     e = plane_eq.repeat_interleave(k, 2).repeat_interleave(k, 3)
