@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--graph", type=int, default=1, help="capture the train step in a hipGraph (N=1 only; falls back to eager)")
     ap.add_argument("--cudnn-benchmark", type=int, default=0)
     ap.add_argument("--optimizer", default="bts", choices=["bts", "torch"], help="bts = fused HIP AdamW (bts_adamw_step)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for plumbing tests")
+    ap.add_argument("--reducer", default="ddp", choices=["ddp", "bts"], help="ddp = torch DDP, bts = bts_amd.parallel.GradAllReducer")
     return ap.parse_args()
 
 
@@ -145,8 +147,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend=args.backend, init_method="env://")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    local = local % torch.cuda.device_count()      # (plumbing tests run several ranks on one GPU over gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -166,9 +169,14 @@ def main():
     if args.channels_last:
         model.encoder.to(memory_format=torch.channels_last)
     net = model
-    if world > 1:
+    reducer = None
+    if world > 1 and args.reducer == "ddp":
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
                                                         broadcast_buffers=False)
+    elif world > 1:
+        from bts_amd.parallel import GradAllReducer, broadcast_parameters
+        broadcast_parameters(model)
+        reducer = GradAllReducer(model.parameters())
     use_graph = bool(args.graph) and world == 1
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
     lr_t = torch.tensor(1e-4, device=dev)      # capturable optimizers read lr from a device tensor
@@ -192,11 +200,16 @@ def main():
         return (1e-4 - 1e-5) * (1 - gstep[0] / total_steps) ** 0.9 + 1e-5     # bts_main.py:456-458
 
     def step_body():
-        opt.zero_grad(set_to_none=not own_opt)
+        if reducer is not None:
+            reducer.zero_grad()                      # flat buckets own the gradients
+        else:
+            opt.zero_grad(set_to_none=not own_opt)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
             outs = net(image, focal)
         loss = crit(outs[4], gt, mask)
         loss.backward()
+        if reducer is not None:
+            reducer.finish()
         if own_opt:
             opt.step(prepared=True)
         else:
@@ -288,7 +301,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s train step (fwd+silog+bwd+AdamW), %dx%d, %d img/GPU, kitti focal scaling" %
                        (args.encoder, args.height, args.width, args.batch),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "grad_exchange": ("none" if world == 1 else ("torch DDP over %s" % args.backend if reducer is None else "bts GradAllReducer over %s" % args.backend)),
                        "encoder": "stock PyTorch-ROCm (%s autocast)" % args.dtype, "decoder": "HIP kernels via libbts_amd.so", "launch": graph_note, "optimizer": "bts_adamw_step (fused HIP)" if own_opt else "torch.optim.AdamW(fused)",
                        "final_loss": round(final_loss, 5)},
         }

@@ -384,7 +384,7 @@ static int flat_blocks(long total) {
 
 static int bn_parts(long M, int CV) {
     int bxl; dim3 g;
-    pick_grid(M, CV, bxl, g, 1024);
+    pick_grid(M, CV, bxl, g, 512);
     return (int)g.x;
 }
 extern "C" long bts_bn_stats_workspace_bytes(long M, int C) {
@@ -399,7 +399,7 @@ extern "C" int bts_bn_stats(const void* x, int dtype, int stride, long M, int C,
     BTS_CHECK_ARG((dtype == BTS_F32 || dtype == BTS_BF16) && vec_ok(dtype, C, stride, x));
     const int V = dtype == BTS_F32 ? 4 : 8, CV = C / V, Cpad = (C + 7) / 8 * 8;
     int bxl; dim3 grid;
-    pick_grid(M, CV, bxl, grid, 1024);
+    pick_grid(M, CV, bxl, grid, 512);
     Shape2 s{M, CV};
     hipStream_t st = (hipStream_t)stream;
 #define L_(TT, dummy) hipLaunchKernelGGL(bn_stats_partial_kernel<TT>, grid, dim3(256), 0, st, x, stride, s, bxl, (float*)workspace, Cpad)
@@ -445,7 +445,7 @@ extern "C" int bts_bn_bwd_reduce(const void* dy, int dy_stride, const void* x, i
     BTS_CHECK_ARG((dtype == BTS_F32 || dtype == BTS_BF16) && vec_ok(dtype, C, x_stride, x) && vec_ok(dtype, C, dy_stride, dy));
     const int V = dtype == BTS_F32 ? 4 : 8, CV = C / V, Cpad = (C + 7) / 8 * 8;
     int bxl; dim3 grid;
-    pick_grid(M, CV, bxl, grid, 1024);
+    pick_grid(M, CV, bxl, grid, 512);
     Shape2 s{M, CV};
     hipStream_t st = (hipStream_t)stream;
 #define L_(TT, dummy) hipLaunchKernelGGL(bn_bwd_partial_kernel<TT>, grid, dim3(256), 0, st, dy, dy_stride, x, x_stride, s, bxl, mean, invstd, gamma, beta, relu, (float*)workspace, Cpad)
