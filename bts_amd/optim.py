@@ -83,8 +83,9 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
                 st["step"] += 1
-                if not (p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32):
-                    raise RuntimeError("FusedAdamW needs contiguous f32 parameters and gradients")
+                dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+                if not (dense and p.grad.stride() == p.stride() and p.dtype == torch.float32 and p.grad.dtype == torch.float32):
+                    raise RuntimeError("FusedAdamW needs dense f32 parameters with identically laid out gradients")
             t = self._table(gi, plist)
             b1, b2 = g["betas"]
             hyper = self._hyper[gi]
