@@ -120,6 +120,13 @@ def main():
         res += conv_case("upconv1", bf, 32, [64], 9, 1, True, B, 176, 608, a.iters, ("fwd", "wgrad"))
         res += conv_case("conv1", bf, 32, [32, 4], 9, 1, False, B, 352, 1216, a.iters, ("fwd", "wgrad"))
         res += conv_case("conv5_f32", f32, 512, [512, 384], 9, 1, False, B, 22, 76, max(2, a.iters // 3), ("fwd",))
+    if a.set == "fwd":   # forward-only subset for A/B and ablation runs
+        B = 8
+        res += conv_case("conv5", bf, 512, [512, 384], 9, 1, False, B, 22, 76, a.iters, ("fwd",))
+        res += conv_case("daspp_conv", bf, 128, [256, 128, 128, 128, 128, 128], 9, 1, False, B, 44, 152, a.iters, ("fwd",))
+        res += conv_case("conv2", bf, 64, [64, 96, 1], 9, 1, False, B, 176, 608, a.iters, ("fwd",))
+        res += conv_case("upconv1", bf, 32, [64], 9, 1, True, B, 176, 608, a.iters, ("fwd",))
+        res += conv_case("conv1", bf, 32, [32, 4], 9, 1, False, B, 352, 1216, a.iters, ("fwd",))
     if a.set in ("all", "lpg"):
         for k in (8, 4, 2):
             res += lpg_case(8, 352, 1216, k, a.iters)      # train shape (configs[2], per GPU)
