@@ -299,11 +299,12 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK a) {
 
 // segment lookup for the strength-reduced address path: index, base pointer, byte stride, channel byte offset
 __device__ __forceinline__ void pick_seg_b(const ConvK& a, int cv, int vec_bytes, int& seg, const char*& sp, uint32_t& sb,
-                                           uint32_t& coffB) {
+                                           uint32_t& coffB, int& seg_end) {
     seg = 0;
     sp = a.seg_ptr[0];
     sb = a.seg_sb[0];
     int coff = cv;
+    seg_end = a.nseg > 1 ? a.seg_cum[1] : a.KV;
 #pragma unroll
     for (int s = 1; s < BTS_MAX_SEG; ++s) {
         if (s < a.nseg && cv >= a.seg_cum[s]) {
@@ -311,6 +312,7 @@ __device__ __forceinline__ void pick_seg_b(const ConvK& a, int cv, int vec_bytes
             sp = a.seg_ptr[s];
             sb = a.seg_sb[s];
             coff = cv - a.seg_cum[s];
+            seg_end = s + 1 < a.nseg ? a.seg_cum[s + 1] : a.KV;
         }
     }
     coffB = (uint32_t)(coff * vec_bytes);
@@ -396,36 +398,61 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
     // Address generation (prep) and DMA issue (fire) are split so that the VALU work of chunk c+NS-1 runs
     // while this wave would otherwise sit in s_waitcnt/s_barrier.  fire always issues exactly G DMA
     // instructions per thread (chunks past the end fetch the zero page): the vmcnt arithmetic is uniform.
+    // Source pointers of the next DMA group.  Within one (tap, segment) run consecutive chunks just advance every
+    // pointer by 128 B (2 VALU adds per row); the full per-row address / padding computation below runs only when this
+    // lane crosses into the next tap or input segment.  (Profiled r1: the un-cached version spent as long in address
+    // VALU as in MFMA, and the two waves a SIMD hosts are barrier-locked, so the two did not overlap.)
     const char* srcA[RA];
     const char* srcB[RB];
+    uint32_t okmask = 0;         // bit i: row i of the current tap is inside the image
+    int run_left = 0;            // chunks this lane can still take from the current (tap, segment) run
+#pragma unroll
+    for (int i = 0; i < RA; ++i) srcA[i] = wrow[i] ? wrow[i] + (size_t)vec * (VEC * ES) : zero;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) srcB[i] = zero;
     auto prep_chunk = [&](int chunk) {
         const int kv = chunk * 8 + vec;
         const bool kok = kv < TKV;
-        const uint32_t kB = (uint32_t)kv * (VEC * ES);
+        if (chunk > 0) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) srcA[i] = (kok && wrow[i]) ? wrow[i] + kB : zero;
-        int dy = 0, dx = 0, ioy = 0, iox = 0, toff = 0;
-        int seg; const char* sp; uint32_t sb, coffB;
-        pick_seg_b(a, cv, VEC * ES, seg, sp, sb, coffB);
-        if (kok) {
+            for (int i = 0; i < RA; ++i) srcA[i] = (kok && wrow[i]) ? srcA[i] + 128 : zero;   // weights are linear in kv
+        } else if (!kok) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) srcA[i] = zero;
+        }
+        if (!kok) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) srcB[i] = zero;
+            return;
+        }
+        if (run_left > 0) {                            // same tap, same segment: next 128 B of every live row
+            --run_left;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) srcB[i] = ((okmask >> i) & 1u) ? srcB[i] + 128 : zero;
+        } else {
+            int dy, dx, ioy, iox;
+            int seg, seg_end; const char* sp; uint32_t sb, coffB;
+            pick_seg_b(a, cv, VEC * ES, seg, sp, sb, coffB, seg_end);
             decode_tap(sTap[phase * a.T + tap], dy, dx, ioy, iox);
-            toff = sTapOff[phase * a.T + tap];
-        }
-        if (seg != curseg) {                           // rare: the lane crossed into another input segment
-            curseg = seg;
+            const int toff = sTapOff[phase * a.T + tap];
+            if (seg != curseg) {
+                curseg = seg;
 #pragma unroll
-            for (int i = 0; i < RB; ++i) rowoff[i] = rowpix[i] * sb;
-        }
-        const char* base = sp + (long)coffB + (long)(toff * (int)sb);
+                for (int i = 0; i < RB; ++i) rowoff[i] = rowpix[i] * sb;
+            }
+            const char* base = sp + (long)coffB + (long)(toff * (int)sb);
+            okmask = 0;
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const bool ok = kok && (unsigned)(py[i] + dy) < (unsigned)a.Hg && (unsigned)(px[i] + dx) < (unsigned)a.Wg;
-            srcB[i] = ok ? base + rowoff[i] : zero;
+            for (int i = 0; i < RB; ++i) {
+                const bool ok = (unsigned)(py[i] + dy) < (unsigned)a.Hg && (unsigned)(px[i] + dx) < (unsigned)a.Wg;
+                okmask |= ok ? (1u << i) : 0u;
+                srcB[i] = ok ? base + rowoff[i] : zero;
+            }
+            // how many more chunks stay inside this segment of this tap (cv advances by 8 vectors per chunk)
+            run_left = (seg_end - 1 - cv) >> 3;
         }
-        if (kok) {
-            cv += 8;
-            while (cv >= a.KV) { cv -= a.KV; ++tap; }
-        }
+        cv += 8;
+        while (cv >= a.KV) { cv -= a.KV; ++tap; }
     };
     auto fire_chunk = [&](int buf) {
         char* sA = smem + buf * BUF;
