@@ -13,6 +13,7 @@ its concatenated input as a list of segments.
 """
 import torch
 
+from . import chain as chain_mod
 from . import ops
 from ._lib import ACT_ELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BtsAmdError
 from .conv import ConvLayer
@@ -85,6 +86,7 @@ class DecoderPlan:
         add("conv1.0", nf // 16, [nf // 16, 4], 9)
         add("get_depth.0", 1, [nf // 16], 9)
         self.layers = L
+        self.chain_cache = {}
 
 
 class DecoderRun:
@@ -240,6 +242,29 @@ class DecoderRun:
             self.tape.append(bwd)
         return y
 
+    def chain_fused(self, name, x, k):
+        """Inference-only: whole reduction_1x1 chain (+ plane head + LPG for k > 1) in one kernel
+        (csrc/lpg_chain.hip).  Returns None when the chain shape has no instantiation."""
+        keys = self.plan.reduc[name]
+        ws = [self.P[key + ".weight"] for key in keys]
+        c0, same = ws[0].shape[1], ws[0].shape[0] == ws[0].shape[1]
+        if not chain_mod.supported(c0, same, k) or x.t.shape[3] != c0:
+            return None
+        ck = (name, self.dtype, tuple((w.data_ptr(), w._version) for w in ws))
+        cache = self.plan.chain_cache
+        if cache.get(name, (None,))[0] != ck:
+            cache[name] = (ck, chain_mod.pack_chain(ws, self.dtype))
+        return Act(chain_mod.chain_fwd(x.t, cache[name][1], c0, same, k, self.max_depth))
+
+    def lpg_branch(self, name, x, k):
+        """reduction chain + LPG head: fused kernel when no gradient is recorded, layer-wise otherwise."""
+        if not self.record:
+            d = self.chain_fused(name, x, k)
+            if d is not None:
+                return d
+        y = self.chain(name, x)
+        return y if k == 1 else self.head(y, k)
+
     def chain(self, name, x):
         keys = self.plan.reduc[name]
         for key in keys[:-1]:
@@ -275,15 +300,15 @@ class DecoderRun:
             cat = cat + [dk[d]]
         df = self.conv("daspp_conv.0", [i4, dk[3], dk[6], dk[12], dk[18], dk[24]], ACT_ELU)   # :219-220
 
-        d8 = self.head(self.chain("reduc8x8", df), 8)                       # :222-228
+        d8 = self.lpg_branch("reduc8x8", df, 8)                             # :222-228
         u3 = self.bn(self.conv("upconv3.conv", [df], ACT_ELU), "bn3", 1.1e-5)        # :231-232
         i3 = self.conv("conv3.0", [u3, s1, self.slots([d8], [4], N, H // 4, W // 4)], ACT_ELU)   # :229, 233-234
-        d4 = self.head(self.chain("reduc4x4", i3), 4)                       # :236-242
+        d4 = self.lpg_branch("reduc4x4", i3, 4)                             # :236-242
         u2 = self.bn(self.conv("upconv2.conv", [i3], ACT_ELU), "bn2", 1.1e-5)        # :245-246
         i2 = self.conv("conv2.0", [u2, s0, self.slots([d4], [2], N, H // 2, W // 2)], ACT_ELU)   # :243, 247-248
-        d2 = self.head(self.chain("reduc2x2", i2), 2)                       # :250-256
+        d2 = self.lpg_branch("reduc2x2", i2, 2)                             # :250-256
         u1 = self.conv("upconv1.conv", [i2], ACT_ELU)                       # :258
-        r1 = self.chain("reduc1x1", u1)                                     # :259
+        r1 = self.lpg_branch("reduc1x1", u1, 1)                             # :259
         i1 = self.conv("conv1.0", [u1, self.slots([r1, d2, d4, d8], [1, 1, 1, 1], N, H, W)], ACT_ELU)   # :260-261
         scale_n = None
         if self.dataset == "kitti":                                         # :263-264

@@ -86,6 +86,18 @@ int bts_lpg_head_bwd(const float* raw, int raw_stride, const float* grad_depth,
                      void* grad_raw, int grad_dtype, int grad_stride, int grad_pad,
                      int batch, int in_h, int in_w, int upratio, float max_depth, bts_stream_t stream);
 
+/* Fused inference LPG head: the whole reduction_1x1 chain (1x1 conv + ELU, halving the channels down to 8,
+ * bts.py:83-108) + plane parameters + normalisation + LPG + /max_depth in ONE pass over the dense feature map
+ * (x is read once, depth written once; activations stay in registers, weights in LDS).
+ *   x        NHWC [cells][x_stride] in `dtype`, c0 input channels
+ *   same_first 1: the first layer is c0 -> c0 (reduc8x8, bts.py:171), 0: c0 -> c0/2
+ *   w_frags  all layers' weights packed in MFMA A-fragment order (bts_amd/chain.py::pack_chain), w_bytes total
+ *   upratio  8/4/2: out = depth [B][h*k][w*k] (already divided by max_depth); 1: out = sigmoid map [cells] (reduc1x1)
+ * Returns BTS_ERR_UNSUPPORTED for chain shapes that have no instantiation (caller falls back to the layer-wise path). */
+int bts_lpg_chain_fwd(const void* x, int dtype, int x_stride, int c0, int same_first, const void* w_frags,
+                      int w_bytes, float* out, long cells, int in_h, int in_w, int upratio, float max_depth,
+                      bts_stream_t stream);
+
 /* Gather up to 4 single-channel f32 maps into channels 0..n-1 of an NHWC buffer (the depth-map
  * slots of the concat inputs of conv3 / conv2 / conv1, bts.py:233, 247, 260): dst pixel (n,y,x)
  * channel s = src[s][n][y*ds[s]][x*ds[s]] where src[s] is [N][H*ds[s]][W*ds[s]]

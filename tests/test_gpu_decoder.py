@@ -204,3 +204,27 @@ def test_fused_adamw_matches_torch_adamw():
         assert set(sa["state"][k].keys()) == {"step", "exp_avg", "exp_avg_sq"}
         assert rel(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"]) < 5e-5   # torch fuses the lerp differently
     ob.load_state_dict(sa)          # state written by one loads in the other
+
+
+@pytest.mark.parametrize("nf,feat", [(512, [96, 96, 192, 384, 2208]), (128, [8, 8, 16, 24, 40])])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_fused_inference_chain_matches_layerwise(nf, feat, dt, tol):
+    """no-grad forward uses the fused reduction-chain + LPG kernel (csrc/lpg_chain.hip); it must agree with the
+    layer-wise path (taken when gradients are recorded) and, in f32, with the oracle to 1e-4."""
+    B, H, W = 2, 64, 96
+    gen = torch.Generator().manual_seed(41)
+    P = O.make_decoder_params(feat, nf, gen, randomize_bn=True)
+    feats = O.make_features(feat, B, H, W, gen)
+    focal = O.synth_focal(B, "kitti")
+    dec, _ = build(feat, nf, "kitti", P, dtype=dt, train=False)
+    fs = [f.to(DEV) for f in feats]
+    with torch.no_grad():
+        fused = dec(fs, focal.to(DEV))
+    layerwise = dec([f.clone().requires_grad_(True) for f in fs], focal.to(DEV))
+    for a, b in zip(fused, layerwise):
+        assert torch.isfinite(a).all()
+        assert rel(a, b) < tol
+    if dt == torch.float32:
+        ref, _ = O.decoder_forward(P, feats, focal, 80.0, "kitti", False)
+        for a, r in zip(fused, ref):
+            assert rel(a, r) < 1e-4

@@ -86,6 +86,26 @@ def lpg_case(B, H, W, k, iters):
     return out
 
 
+def chain_cases(B, H, W, dt, iters):
+    """Fused inference LPG heads (reduction chain + plane + LPG in one pass) at bts_size 512."""
+    from bts_amd import chain
+    out = []
+    esz = 4 if dt == torch.float32 else 2
+    for k, c0, same, dims in ((8, 128, 1, [128, 128, 64, 32, 16, 8, 3]), (4, 128, 0, [128, 64, 32, 16, 8, 3]),
+                               (2, 64, 0, [64, 32, 16, 8, 3]), (1, 32, 0, [32, 16, 8, 1])):
+        h, w = H // k, W // k
+        ws = [torch.randn(dims[i + 1], dims[i], 1, 1, device=DEV) * (1.0 / dims[i]) ** 0.5 for i in range(len(dims) - 1)]
+        frags = chain.pack_chain(ws, dt)
+        x = torch.randn(B, h, w, c0, device=DEV).to(dt)
+        t = timeit(lambda: chain.chain_fwd(x, frags, c0, same, k, 80.0), iters)
+        cells = B * h * w
+        byts = cells * (c0 * esz + 4 * k * k)
+        macs = cells * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+        out.append(dict(case="lpg_chain_fwd k=%d C0=%d %s B=%d %dx%d" % (k, c0, "bf16" if esz == 2 else "f32", B, H, W), sec=t,
+                        alg_gbs=byts / t / 1e9, alg_bytes=byts, tflops=2 * macs / t / 1e12))
+    return out
+
+
 def misc_cases(B, H, W, iters):
     out = []
     est = torch.rand(B, 1, H, W, device=DEV) * 70 + 1
@@ -132,6 +152,10 @@ def main():
             res += lpg_case(8, 352, 1216, k, a.iters)      # train shape (configs[2], per GPU)
         for k in (8, 4, 2):
             res += lpg_case(32, 704, 1216, k, a.iters)     # inference shape (configs[4])
+    if a.set in ("all", "chain"):
+        res += chain_cases(8, 352, 1216, bf, a.iters)
+        res += chain_cases(32, 704, 1216, bf, a.iters)
+        res += chain_cases(8, 352, 1216, f32, a.iters)
     if a.set in ("all", "misc"):
         res += misc_cases(8, 352, 1216, a.iters)
     for r in res:
