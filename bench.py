@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--graph", type=int, default=1, help="capture the train step in a hipGraph (N=1 only; falls back to eager)")
     ap.add_argument("--cudnn-benchmark", type=int, default=0)
     ap.add_argument("--optimizer", default="bts", choices=["bts", "torch"], help="bts = fused HIP AdamW (bts_adamw_step)")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="infer = BASELINE.json configs[4]: no-grad forward, DenseNet161 704x1216 batch 32 (secondary config)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for plumbing tests")
     ap.add_argument("--reducer", default="ddp", choices=["ddp", "bts"], help="ddp = torch DDP, bts = bts_amd.parallel.GradAllReducer")
     return ap.parse_args()
@@ -138,11 +140,72 @@ def cpu_baseline_subprocess(args, timeout_s=240):
                 "sample": "cpu baseline exceeded %d s on this host and was cut" % timeout_s}
 
 
+def infer_main(args):
+    """configs[4]: inference-only path (bts_test.py:119), batch 32 at 704x1216, bf16; images/s of the no-grad forward
+    (fused LPG heads, no tape) + AbsRel of the bf16 depth against the f32 CPU oracle on ONE image of the same inputs."""
+    from bts_amd import _lib, profiler
+    from bts_amd.model import BtsModel, weights_init_xavier
+    from oracle import bts_oracle as O
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    _lib.load()
+    H, W, B = (704, 1216, 32) if (args.height, args.width, args.batch) == (352, 1216, 8) else (args.height, args.width, args.batch)
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    params = NS(encoder=args.encoder, max_depth=80.0, dataset="kitti", bts_size=512, decoder_dtype=cdt)
+    torch.manual_seed(0)
+    model = BtsModel(params)
+    model.decoder.apply(weights_init_xavier)
+    model.eval()
+    gen = torch.Generator().manual_seed(99)
+    image = torch.randn(B, 3, H, W, generator=gen)
+    focal = O.synth_focal(B, "kitti")
+    ref_depth = None
+    if not args.no_cpu_baseline:
+        torch.set_num_threads(min(os.cpu_count() or 1, 64))
+        t0 = time.time()
+        with torch.no_grad():
+            feats = model.encoder(image[:1])
+            P = {k: v for k, v in model.decoder.state_dict().items()}
+            ref, _ = O.decoder_forward(P, feats, focal[:1], 80.0, "kitti", False)
+        cpu_s = time.time() - t0
+        ref_depth = ref[4]
+    model.to(dev)
+    image_d, focal_d = image.to(dev), focal.to(dev)
+
+    def step():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
+            return model(image_d, focal_d)
+    for _ in range(max(args.warmup, 1)):
+        outs = step()
+    prof = profiler.enable() if not args.no_kernel_events else None
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        outs = step()
+    torch.cuda.synchronize()
+    elapsed = time.time() - t0
+    out = {"metric": "images/sec (inference forward) DenseNet161-BTS 704x1216", "value": round(B * args.steps / elapsed, 3),
+           "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "%s no-grad forward, %dx%d, batch %d (BASELINE.json configs[4])" % (args.encoder, H, W, B)}}
+    if prof is not None:
+        profiler.disable()
+        out.update(prof.summary(PEAK[args.dtype], HBM_PEAK_GBS, args.steps))
+    if ref_depth is not None:
+        est = outs[4][:1].float().cpu()
+        out["absrel_vs_cpu_oracle"] = round(((est - ref_depth).abs() / ref_depth).mean().item(), 6)
+        out["cpu_baseline"] = {"value": round(1.0 / cpu_s, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "oracle encoder+decoder forward, f32, 1 image %dx%d (%.1f s)" % (H, W, cpu_s)}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)), flush=True)
         return
+    if args.mode == "infer":
+        return infer_main(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -12,6 +12,7 @@ import ctypes as C
 
 import torch
 
+from . import profiler
 from ._lib import call, dtype_code, stream_ptr
 from .ops import pix_stride
 
@@ -59,6 +60,8 @@ def chain_fwd(x, frags, c0, same_first, k, max_depth):
     """x: NHWC [N,h,w,C0(+pad)] -> depth [N,h*k,w*k] f32 (k in 8/4/2, already / max_depth) or sigmoid map [N,h,w] (k = 1)."""
     N, h, w, _ = x.shape
     out = torch.empty((N, h * k, w * k) if k > 1 else (N, h, w), dtype=torch.float32, device=x.device)
+    if profiler.ACTIVE is not None:      # algorithmic bytes: C0 input channels read once + k*k f32 written
+        profiler.note("lpg_head_chain_fwd<k=%d>" % k, "hbm", N * h * w * (c0 * x.element_size() + 4 * k * k))
     call("bts_lpg_chain_fwd", C.c_void_p(x.data_ptr()), dtype_code(x.dtype), pix_stride(x), c0, int(same_first),
          C.c_void_p(frags.data_ptr()), frags.numel(), C.c_void_p(out.data_ptr()), N * h * w, h, w, k, float(max_depth),
          stream_ptr())

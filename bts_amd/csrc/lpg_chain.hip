@@ -167,12 +167,28 @@ __global__ __launch_bounds__(256) void lpg_chain_fwd_kernel(const ChainK a) {
     __syncthreads();
     const int g = lane >> 5, cl = lane & 31;
     const long ntiles = (a.cells + 31) / 32;
-    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    // Software prefetch: the input fragments of the wave's NEXT tile are requested before the MFMA chain of the
+    // current one, so every wave keeps two tiles of loads in flight (the chains are short: without this the kernel is
+    // latency-bound at ~40 % of HBM).  Skipped for the 128 -> 128 head, which already uses the whole register file.
+    constexpr bool kPrefetch = !(SAME_FIRST && C0 >= 128);
+    const long tstep = (long)gridDim.x * 4;
+    long tile = (long)blockIdx.x * 4 + wave;
+    typename Act<T>::template Regs<C0> in, in_next;
+    auto load_tile = [&](long t, typename Act<T>::template Regs<C0>& dst) {
+        const long c = t * 32 + cl;
+        if constexpr (T::kBytes == 2) load_input_bf16<C0>(a.x, (size_t)c, a.x_stride, t < ntiles && c < a.cells, g, dst);
+        else load_input_f32<C0>(a.x, (size_t)c, a.x_stride, t < ntiles && c < a.cells, g, dst);
+    };
+    if (kPrefetch && tile < ntiles) load_tile(tile, in_next);
+    for (; tile < ntiles; tile += tstep) {
         const long cell = tile * 32 + cl;
         const bool ok = cell < a.cells;
-        typename Act<T>::template Regs<C0> in;
-        if constexpr (T::kBytes == 2) load_input_bf16<C0>(a.x, (size_t)cell, a.x_stride, ok, g, in);
-        else load_input_f32<C0>(a.x, (size_t)cell, a.x_stride, ok, g, in);
+        if constexpr (kPrefetch) {
+            in = in_next;
+            load_tile(tile + tstep, in_next);
+        } else {
+            load_tile(tile, in);
+        }
         float res[4];
         if constexpr (SAME_FIRST) {
             typename Act<T>::template Regs<C0> nxt;
@@ -232,7 +248,10 @@ int launch_chain(const ChainK& k, hipStream_t st) {
     }
     const long ntiles = (k.cells + 31) / 32;
     long blocks = (ntiles + 3) / 4;
-    const long cap = 256 * (k.w_bytes > 80 * 1024 ? 1 : 2) * 2;       // a few resident workgroups per CU, grid-stride beyond
+    // resident workgroups per CU allowed by LDS (weights) and registers; grid-stride beyond that
+    int per_cu = k.w_bytes > 80 * 1024 ? 1 : (k.w_bytes > 40 * 1024 ? 2 : (k.w_bytes > 20 * 1024 ? 4 : 6));
+    if (C0 >= 128 && per_cu > 2) per_cu = 2;
+    const long cap = 256l * per_cu;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), (size_t)k.w_bytes, st, k);
     BTS_LAUNCH_CHECK();
