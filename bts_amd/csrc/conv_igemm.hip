@@ -57,7 +57,6 @@ struct ConvK {
     int dz_stride;
     float* dw;
     int n_col_tiles, nchunks, chunks_per_split;
-    int ablate;   // diagnostics only (BTS_CONV_ABLATE): 1 = no DMA after the prologue, 2 = no MFMA, 4 = no fragment reads
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -497,8 +496,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
         for (int i = 0; i < TM; ++i) fa[0][i] = *(const u32x4_t*)(sT + offA[i] + (((0 + fk) ^ swz) << 4));
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[0][j] = *(const u32x4_t*)(sT + offB[j] + (((0 + fk) ^ swz) << 4));
-        if (!(a.ablate & 1)) fire_chunk(wbuf);
-        if (a.ablate & 4) { rbuf = rbuf + 1 == NS ? 0 : rbuf + 1; wbuf = wbuf + 1 == NS ? 0 : wbuf + 1; continue; }
+        fire_chunk(wbuf);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (s < 3) {
@@ -508,17 +506,10 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
                 for (int j = 0; j < TN; ++j) fb[(s + 1) & 1][j] = *(const u32x4_t*)(sT + offB[j] + (((2 * (s + 1) + fk) ^ swz) << 4));
             }
             __builtin_amdgcn_sched_barrier(0);   // keep the read-ahead ABOVE this k-step's MFMAs (hipcc sinks it otherwise)
-            if (a.ablate & 2) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[s & 1][i]));
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb[s & 1][j]));
-            } else {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
-            }
+                for (int j = 0; j < TN; ++j) Mma<T>::run(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
         rbuf = rbuf + 1 == NS ? 0 : rbuf + 1;
@@ -980,10 +971,6 @@ extern "C" int bts_conv_fwd(const bts_conv_desc_t* d, bts_stream_t stream) {
     k.accumulate = d->accumulate;
     k.out_scale = d->out_scale;
     k.out_scale_n = d->out_scale_n;
-    {
-        static const int abl = [] { const char* e = getenv("BTS_CONV_ABLATE"); return e ? atoi(e) : 0; }();
-        k.ablate = abl;
-    }
     const int ob = k.y_f32 ? 16 : 8;
     k.vec_store = (d->Cout % 4 == 0) && (d->y_stride % 4 == 0) && (((uintptr_t)d->y & (ob - 1)) == 0);
     return d->dtype == BTS_F32 ? launch_fwd<F32>(k, (hipStream_t)stream) : launch_fwd<BF16>(k, (hipStream_t)stream);

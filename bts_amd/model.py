@@ -177,9 +177,8 @@ class local_planar_guidance(nn.Module):
 # ---------------------------------------------------------------------------------------------
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod, focal, n_feat, names, *tensors):
+    def forward(ctx, mod, focal, n_feat, names, record, *tensors):
         feats, params = tensors[:n_feat], tensors[n_feat:]
-        record = any(ctx.needs_input_grad)
         P = dict(zip(names, (p.detach() for p in params)))
         for k, b in mod.named_buffers():
             P[k] = b
@@ -194,7 +193,7 @@ class _DecoderFn(torch.autograd.Function):
         gfeats, grads = ctx.run.backward(gouts)
         ctx.run = None
         gp = [grads.get(n) for n in ctx.names]
-        return (None, None, None, None) + tuple(gfeats) + tuple(gp)
+        return (None, None, None, None, None) + tuple(gfeats) + tuple(gp)
 
 
 class bts(nn.Module):
@@ -253,7 +252,10 @@ class bts(nn.Module):
         feats = list(features[:5])
         require_gpu(feats[0])
         names, params = zip(*self.named_parameters())
-        return _DecoderFn.apply(self, focal, len(feats), names, *feats, *params)
+        # record the backward tape only when autograd will ask for it; the no-grad path (bts_test.py:118-119,
+        # online_eval) runs the fused inference LPG heads and keeps no activations
+        record = torch.is_grad_enabled() and (any(f.requires_grad for f in feats) or any(p.requires_grad for p in params))
+        return _DecoderFn.apply(self, focal, len(feats), names, record, *feats, *params)
 
 
 # ---------------------------------------------------------------------------------------------

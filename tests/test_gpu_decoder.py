@@ -218,9 +218,16 @@ def test_fused_inference_chain_matches_layerwise(nf, feat, dt, tol):
     focal = O.synth_focal(B, "kitti")
     dec, _ = build(feat, nf, "kitti", P, dtype=dt, train=False)
     fs = [f.to(DEV) for f in feats]
+    from bts_amd import profiler
+    prof = profiler.enable()
     with torch.no_grad():
         fused = dec(fs, focal.to(DEV))
+    names = {r[0] for r in prof.records}
     layerwise = dec([f.clone().requires_grad_(True) for f in fs], focal.to(DEV))
+    names2 = {r[0] for r in prof.records} - names
+    profiler.disable()
+    assert any(n.startswith("lpg_head_chain_fwd") for n in names), names       # the fused kernel really ran
+    assert not any(n.startswith("lpg_head_chain_fwd") for n in names2) and any(n.startswith("lpg_head_fwd") for n in names2)
     for a, b in zip(fused, layerwise):
         assert torch.isfinite(a).all()
         assert rel(a, b) < tol
