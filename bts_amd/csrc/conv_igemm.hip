@@ -57,6 +57,7 @@ struct ConvK {
     int dz_stride;
     float* dw;
     int n_col_tiles, nchunks, chunks_per_split;
+    int halo_ok;   // every tap within radius 1 on an unscaled same-size input: eligible for conv_halo
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -520,6 +521,158 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Narrow-layer kernel: 3x3 (radius-1) convolutions with <= 32 output channels per workgroup, on a 2-D
+// pixel tile with an LDS halo.
+//
+// The implicit-GEMM kernels above re-fetch every input pixel once per tap (9x for 3x3), which is harmless
+// when the weights dominate the staging traffic (Cout >= 128) but makes the full-resolution layers
+// (conv1/conv2/upconv1/upconv2/get_depth and their data-gradients: Cout <= 64, K <= 1.5 k) bound by the
+// L2 -> LDS path.  Here a workgroup stages, per 128-byte channel chunk, the (TH+2) x 34 input patch ONCE
+// (zero page outside the image = padding) plus the chunk's weights for every tap, and all taps read their
+// B fragments from the same patch at shifted rows.  Sub-pixel up-convolution (4 phases x 4 taps, bts.py:69-80)
+// shares one patch across the four phases.  One wave per tile row of 32 pixels; lanes <-> pixels,
+// registers <-> output channels, same epilogue conventions as conv_epilogue.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int TH, int NG, int TPG>
+__global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
+    constexpr int TW = 32, PW = TW + 2, PR = (TH + 2) * PW;    // patch rows (pixels)
+    constexpr int NT = NG * TPG;                                // taps in total (9 or 16)
+    constexpr int WR_ROWS = NT * 32;                            // weight rows in LDS
+    constexpr int NTHR = 64 * TH, RP = NTHR / 8;                // rows per DMA pass
+    constexpr int VEC = T::kVec, ES = T::kBytes;
+    constexpr int PR_PAD = (PR + RP - 1) / RP * RP;
+    __shared__ __attribute__((aligned(16))) char smem[(PR_PAD + WR_ROWS) * 128];
+    char* sP = smem;
+    char* sW = smem + PR_PAD * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (a.Wg + TW - 1) / TW, tiles_y = (a.Hg + TH - 1) / TH;
+    int L = remap_xcd(blockIdx.x, tiles_x * tiles_y * a.N);
+    const int tx = L % tiles_x; L /= tiles_x;
+    const int ty = L % tiles_y;
+    const int n = L / tiles_y;
+    const int co_tile = blockIdx.y;
+    const int x0 = tx * TW, y0 = ty * TH;
+
+    const int pc = tid & 7, srow = tid >> 3;
+    const int vec = pc ^ ((srow >> 1) & 7);
+    const char* zero = (const char*)kZeroPage;
+    const int nchunks = (a.KV + 7) >> 3;
+
+    f32x16_t acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+    const int frow = lane & 31, fk = lane >> 5;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const int cv = cc * 8 + vec;
+        const bool kok = cv < a.KV;
+        // ---- patch: every input pixel of the tile + halo, once ----
+        {
+            int seg, seg_end; const char* sp; uint32_t sb, coffB;
+            pick_seg_b(a, kok ? cv : 0, VEC * ES, seg, sp, sb, coffB, seg_end);
+#pragma unroll
+            for (int pass = 0; pass < PR_PAD / RP; ++pass) {
+                const int r = pass * RP + srow;
+                const int pyy = r / PW, pxx = r - pyy * PW;
+                const int iy = y0 - 1 + pyy, ix = x0 - 1 + pxx;
+                const bool ok = kok && r < PR && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx;
+                const char* src = zero;
+                if (ok) src = sp + (size_t)((uint32_t)((n * a.Hx + iy) * a.Wx + ix) * sb) + coffB;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sP + (pass * RP + wave * 8) * 128), 16, 0, 0);
+            }
+        }
+        // ---- weights of this channel chunk, all taps: row = tap*32 + co ----
+#pragma unroll
+        for (int pass = 0; pass < WR_ROWS / RP; ++pass) {
+            const int r = pass * RP + srow;
+            const int t = r >> 5, co = co_tile * 32 + (r & 31);
+            const char* src = zero;
+            if (kok && co < a.Cout) src = a.w + (((size_t)co * a.Ttot + t) * a.Ktot + (size_t)cv * VEC) * ES;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sW + (pass * RP + wave * 8) * 128), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- all taps from the shared patch ----
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int t = 0; t < TPG; ++t) {
+                int dy, dx, ioy, iox;
+                decode_tap(a.taps[g * TPG + t], dy, dx, ioy, iox);
+                const int prow = (wave + 1 + dy) * PW + (frow + 1 + dx);
+                const int wrow = (g * TPG + t) * 32 + frow;
+                const int pswz = (prow >> 1) & 7, wswz = (wrow >> 1) & 7;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const u32x4_t fb = *(const u32x4_t*)(sP + prow * 128 + (((2 * s + fk) ^ pswz) << 4));
+                    const u32x4_t fa = *(const u32x4_t*)(sW + wrow * 128 + (((2 * s + fk) ^ wswz) << 4));
+                    Mma<T>::run(fa, fb, acc[g]);
+                }
+            }
+        }
+        __syncthreads();      // patch / weights are overwritten by the next chunk
+    }
+
+    // ---- epilogue: lane = pixel (x0 + frow) of tile row `wave`, registers = channels ----
+    const int oy = y0 + wave, ox = x0 + frow;
+    if (oy >= a.Hg || ox >= a.Wg) return;
+    float sc = a.out_scale;
+    if (a.out_scale_n) sc *= a.out_scale_n[n];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const size_t opix = ((size_t)n * a.Hy + (oy * a.osc + (g >> 1))) * a.Wy + (ox * a.osc + (g & 1));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int co = co_tile * 32 + 8 * q + 4 * fk;
+            if (co >= a.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = acc[g][4 * q + e];
+                if (a.act == BTS_ACT_ELU) t = act_elu(t);
+                else if (a.act == BTS_ACT_SIGMOID) t = act_sigmoid(t);
+                else if (a.act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
+                v[e] = t * sc;
+            }
+            const size_t o = opix * a.y_stride + co;
+            if (a.vec_store) {
+                if (a.y_f32) {
+                    float* p = (float*)a.y + o;
+                    f32x4_t t = {v[0], v[1], v[2], v[3]};
+                    if (a.accumulate) { f32x4_t old = *(f32x4_t*)p; t += old; }
+                    *(f32x4_t*)p = t;
+                } else {
+                    uint16_t* p = (uint16_t*)a.y + o;
+                    if (a.accumulate) {
+                        u32x2_t old = *(u32x2_t*)p;
+                        v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                        v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+                    }
+                    u32x2_t t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *(u32x2_t*)p = t;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (co + e >= a.Cout) break;
+                    if (a.y_f32) {
+                        float* p = (float*)a.y + o + e;
+                        *p = a.accumulate ? *p + v[e] : v[e];
+                    } else {
+                        uint16_t* p = (uint16_t*)a.y + o + e;
+                        const float t = a.accumulate ? bf16_bits_to_f32(*p) + v[e] : v[e];
+                        *p = (uint16_t)f32_to_bf16_bits(t);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight-gradient kernel
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -880,6 +1033,10 @@ static int fill_common(const bts_conv_desc_t* d, ConvK& k) {
     }
     k.Cout = d->Cout;
     k.Hy = d->Hy; k.Wy = d->Wy; k.osc = d->osc;
+    k.halo_ok = d->isc == 1 && d->Hx == d->Hg && d->Wx == d->Wg &&
+                ((d->nphase == 1 && d->T == 9 && d->osc == 1) || (d->nphase == 4 && d->T == 4 && d->osc == 2));
+    for (int t = 0; t < k.Ttot && k.halo_ok; ++t)
+        if (d->dy[t] < -1 || d->dy[t] > 1 || d->dx[t] < -1 || d->dx[t] > 1 || d->ioy[t] != 0 || d->iox[t] != 0) k.halo_ok = 0;
     return BTS_OK;
 }
 
@@ -902,6 +1059,20 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
         hipLaunchKernelGGL(kern, grid, dim3(threads), 0, st, k);
     };
     auto go = [&](auto kern, int BM, int BN) { go2(kern, BM, BN, 256); };
+    // narrow radius-1 layers: 2-D tile with LDS halo (see conv_halo)
+    static const int halo_on = [] { const char* e = getenv("BTS_CONV_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (halo_on && use_lds_dma() && k.halo_ok && k.Cout <= 64) {
+        const int co_tiles = ceil_div(k.Cout, 32);
+        if (k.nphase == 4) {
+            dim3 grid(ceil_div(k.Wg, 32) * ceil_div(k.Hg, 8) * k.N, co_tiles);
+            hipLaunchKernelGGL((conv_halo<T, 8, 4, 4>), grid, dim3(512), 0, st, k);
+        } else {
+            dim3 grid(ceil_div(k.Wg, 32) * ceil_div(k.Hg, 4) * k.N, co_tiles);
+            hipLaunchKernelGGL((conv_halo<T, 4, 1, 9>), grid, dim3(256), 0, st, k);
+        }
+        BTS_LAUNCH_CHECK();
+        return BTS_OK;
+    }
     if (use_lds_dma()) {
         // tile / pipeline depth by problem shape (LDS: NS * (BM+BN) * 128 B):
         //   d  128co x 256px, 8 waves, 2 stages ( 96 KiB, 1 WG/CU = 2 waves/SIMD)  [r1: 594-644 TF on conv5/daspp_conv]
