@@ -533,7 +533,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
 // shares one patch across the four phases.  One wave per tile row of 32 pixels; lanes <-> pixels,
 // registers <-> output channels, same epilogue conventions as conv_epilogue.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int TH, int NG, int TPG>
+template <typename T, int TH, int NG, int TPG, bool PERSIST>
 __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
     constexpr int TW = 32, PW = TW + 2, PR = (TH + 2) * PW;    // patch rows (pixels)
     constexpr int NT = NG * TPG;                                // taps in total (9 or 16)
@@ -541,50 +541,47 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
     constexpr int NTHR = 64 * TH, RP = NTHR / 8;                // rows per DMA pass
     constexpr int VEC = T::kVec, ES = T::kBytes;
     constexpr int PR_PAD = (PR + RP - 1) / RP * RP;
-    __shared__ __attribute__((aligned(16))) char smem[(PR_PAD + WR_ROWS) * 128];
-    char* sP = smem;
-    char* sW = smem + PR_PAD * 128;
+    constexpr int NPB = PERSIST ? 2 : 1;                        // patch buffers
+    __shared__ __attribute__((aligned(16))) char smem[(NPB * PR_PAD + WR_ROWS) * 128];
+    char* sW = smem + NPB * PR_PAD * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (a.Wg + TW - 1) / TW, tiles_y = (a.Hg + TH - 1) / TH;
-    int L = remap_xcd(blockIdx.x, tiles_x * tiles_y * a.N);
-    const int tx = L % tiles_x; L /= tiles_x;
-    const int ty = L % tiles_y;
-    const int n = L / tiles_y;
+    const int ntiles = tiles_x * tiles_y * a.N;
     const int co_tile = blockIdx.y;
-    const int x0 = tx * TW, y0 = ty * TH;
-
     const int pc = tid & 7, srow = tid >> 3;
     const int vec = pc ^ ((srow >> 1) & 7);
     const char* zero = (const char*)kZeroPage;
     const int nchunks = (a.KV + 7) >> 3;
-
-    f32x16_t acc[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-
     const int frow = lane & 31, fk = lane >> 5;
-    for (int cc = 0; cc < nchunks; ++cc) {
+
+    auto tile_origin = [&](int tile, int& n, int& y0, int& x0) {
+        const int tx = tile % tiles_x;
+        tile /= tiles_x;
+        y0 = (tile % tiles_y) * TH;
+        n = tile / tiles_y;
+        x0 = tx * TW;
+    };
+    // DMA of one channel chunk of the (TH+2) x 34 input patch (zero page outside the image / beyond K)
+    auto dma_patch = [&](int cc, int n, int y0, int x0, char* sP) {
         const int cv = cc * 8 + vec;
         const bool kok = cv < a.KV;
-        // ---- patch: every input pixel of the tile + halo, once ----
-        {
-            int seg, seg_end; const char* sp; uint32_t sb, coffB;
-            pick_seg_b(a, kok ? cv : 0, VEC * ES, seg, sp, sb, coffB, seg_end);
+        int seg, seg_end; const char* sp; uint32_t sb, coffB;
+        pick_seg_b(a, kok ? cv : 0, VEC * ES, seg, sp, sb, coffB, seg_end);
 #pragma unroll
-            for (int pass = 0; pass < PR_PAD / RP; ++pass) {
-                const int r = pass * RP + srow;
-                const int pyy = r / PW, pxx = r - pyy * PW;
-                const int iy = y0 - 1 + pyy, ix = x0 - 1 + pxx;
-                const bool ok = kok && r < PR && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx;
-                const char* src = zero;
-                if (ok) src = sp + (size_t)((uint32_t)((n * a.Hx + iy) * a.Wx + ix) * sb) + coffB;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sP + (pass * RP + wave * 8) * 128), 16, 0, 0);
-            }
+        for (int pass = 0; pass < PR_PAD / RP; ++pass) {
+            const int r = pass * RP + srow;
+            const int pyy = r / PW, pxx = r - pyy * PW;
+            const int iy = y0 - 1 + pyy, ix = x0 - 1 + pxx;
+            const bool ok = kok && r < PR && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx;
+            const char* src = zero;
+            if (ok) src = sp + (size_t)((uint32_t)((n * a.Hx + iy) * a.Wx + ix) * sb) + coffB;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sP + (pass * RP + wave * 8) * 128), 16, 0, 0);
         }
-        // ---- weights of this channel chunk, all taps: row = tap*32 + co ----
+    };
+    auto dma_weights = [&](int cc) {      // row = tap*32 + co
+        const int cv = cc * 8 + vec;
+        const bool kok = cv < a.KV;
 #pragma unroll
         for (int pass = 0; pass < WR_ROWS / RP; ++pass) {
             const int r = pass * RP + srow;
@@ -593,9 +590,8 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
             if (kok && co < a.Cout) src = a.w + (((size_t)co * a.Ttot + t) * a.Ktot + (size_t)cv * VEC) * ES;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sW + (pass * RP + wave * 8) * 128), 16, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // ---- all taps from the shared patch ----
+    };
+    auto compute = [&](const char* sP, f32x16_t (&acc)[NG]) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
 #pragma unroll
@@ -613,62 +609,109 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
                 }
             }
         }
-        __syncthreads();      // patch / weights are overwritten by the next chunk
-    }
-
-    // ---- epilogue: lane = pixel (x0 + frow) of tile row `wave`, registers = channels ----
-    const int oy = y0 + wave, ox = x0 + frow;
-    if (oy >= a.Hg || ox >= a.Wg) return;
-    float sc = a.out_scale;
-    if (a.out_scale_n) sc *= a.out_scale_n[n];
+    };
+    // lane = pixel (x0 + frow) of tile row `wave`, registers = channels
+    auto epilogue = [&](const f32x16_t (&acc)[NG], int n, int y0, int x0) {
+        const int oy = y0 + wave, ox = x0 + frow;
+        if (oy >= a.Hg || ox >= a.Wg) return;
+        float sc = a.out_scale;
+        if (a.out_scale_n) sc *= a.out_scale_n[n];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const size_t opix = ((size_t)n * a.Hy + (oy * a.osc + (g >> 1))) * a.Wy + (ox * a.osc + (g & 1));
+        for (int g = 0; g < NG; ++g) {
+            const size_t opix = ((size_t)n * a.Hy + (oy * a.osc + (g >> 1))) * a.Wy + (ox * a.osc + (g & 1));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int co = co_tile * 32 + 8 * q + 4 * fk;
-            if (co >= a.Cout) continue;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = acc[g][4 * q + e];
-                if (a.act == BTS_ACT_ELU) t = act_elu(t);
-                else if (a.act == BTS_ACT_SIGMOID) t = act_sigmoid(t);
-                else if (a.act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
-                v[e] = t * sc;
-            }
-            const size_t o = opix * a.y_stride + co;
-            if (a.vec_store) {
-                if (a.y_f32) {
-                    float* p = (float*)a.y + o;
-                    f32x4_t t = {v[0], v[1], v[2], v[3]};
-                    if (a.accumulate) { f32x4_t old = *(f32x4_t*)p; t += old; }
-                    *(f32x4_t*)p = t;
-                } else {
-                    uint16_t* p = (uint16_t*)a.y + o;
-                    if (a.accumulate) {
-                        u32x2_t old = *(u32x2_t*)p;
-                        v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
-                        v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
-                    }
-                    u32x2_t t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *(u32x2_t*)p = t;
-                }
-            } else {
+            for (int q = 0; q < 4; ++q) {
+                const int co = co_tile * 32 + 8 * q + 4 * fk;
+                if (co >= a.Cout) continue;
+                float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (co + e >= a.Cout) break;
+                    float t = acc[g][4 * q + e];
+                    if (a.act == BTS_ACT_ELU) t = act_elu(t);
+                    else if (a.act == BTS_ACT_SIGMOID) t = act_sigmoid(t);
+                    else if (a.act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
+                    v[e] = t * sc;
+                }
+                const size_t o = opix * a.y_stride + co;
+                if (a.vec_store) {
                     if (a.y_f32) {
-                        float* p = (float*)a.y + o + e;
-                        *p = a.accumulate ? *p + v[e] : v[e];
+                        float* p = (float*)a.y + o;
+                        f32x4_t t = {v[0], v[1], v[2], v[3]};
+                        if (a.accumulate) { f32x4_t old = *(f32x4_t*)p; t += old; }
+                        *(f32x4_t*)p = t;
                     } else {
-                        uint16_t* p = (uint16_t*)a.y + o + e;
-                        const float t = a.accumulate ? bf16_bits_to_f32(*p) + v[e] : v[e];
-                        *p = (uint16_t)f32_to_bf16_bits(t);
+                        uint16_t* p = (uint16_t*)a.y + o;
+                        if (a.accumulate) {
+                            u32x2_t old = *(u32x2_t*)p;
+                            v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                            v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+                        }
+                        u32x2_t t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *(u32x2_t*)p = t;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e >= a.Cout) break;
+                        if (a.y_f32) {
+                            float* p = (float*)a.y + o + e;
+                            *p = a.accumulate ? *p + v[e] : v[e];
+                        } else {
+                            uint16_t* p = (uint16_t*)a.y + o + e;
+                            const float t = a.accumulate ? bf16_bits_to_f32(*p) + v[e] : v[e];
+                            *p = (uint16_t)f32_to_bf16_bits(t);
+                        }
                     }
                 }
             }
         }
+    };
+
+    if constexpr (PERSIST) {
+        // K fits one channel chunk: the weights stay in LDS for the whole workgroup, which walks a contiguous range
+        // of tiles with double-buffered patches (the DMA of tile i+1 is in flight under the MFMAs + stores of tile i).
+        const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+        const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
+        if (t_begin >= t_end) return;
+        dma_weights(0);
+        int n, y0, x0;
+        tile_origin(t_begin, n, y0, x0);
+        dma_patch(0, n, y0, x0, smem);
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            const int cur = (tile - t_begin) & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                         // patch `cur` (and the weights) landed; buffer cur^1 is free
+            int nn = 0, ny0 = 0, nx0 = 0;
+            if (tile + 1 < t_end) {
+                tile_origin(tile + 1, nn, ny0, nx0);
+                dma_patch(0, nn, ny0, nx0, smem + (cur ^ 1) * PR_PAD * 128);
+            }
+            f32x16_t acc[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+            compute(smem + cur * PR_PAD * 128, acc);
+            epilogue(acc, n, y0, x0);
+            n = nn; y0 = ny0; x0 = nx0;
+        }
+    } else {
+        int n, y0, x0;
+        tile_origin(remap_xcd(blockIdx.x, ntiles), n, y0, x0);
+        f32x16_t acc[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+        for (int cc = 0; cc < nchunks; ++cc) {
+            dma_patch(cc, n, y0, x0, smem);
+            dma_weights(cc);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(smem, acc);
+            __syncthreads();      // patch / weights are overwritten by the next chunk
+        }
+        epilogue(acc, n, y0, x0);
     }
 }
 
@@ -1063,12 +1106,19 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
     static const int halo_on = [] { const char* e = getenv("BTS_CONV_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
     if (halo_on && use_lds_dma() && k.halo_ok && k.Cout <= 64) {
         const int co_tiles = ceil_div(k.Cout, 32);
+        const bool one_chunk = k.KV <= 8;       // whole K in one 128-byte channel chunk: persistent variant
         if (k.nphase == 4) {
-            dim3 grid(ceil_div(k.Wg, 32) * ceil_div(k.Hg, 8) * k.N, co_tiles);
-            hipLaunchKernelGGL((conv_halo<T, 8, 4, 4>), grid, dim3(512), 0, st, k);
+            const int ntiles = ceil_div(k.Wg, 32) * ceil_div(k.Hg, 8) * k.N;
+            if (one_chunk) hipLaunchKernelGGL((conv_halo<T, 8, 4, 4, true>), dim3(ntiles < 256 ? ntiles : 256, co_tiles), dim3(512), 0, st, k);
+            else hipLaunchKernelGGL((conv_halo<T, 8, 4, 4, false>), dim3(ntiles, co_tiles), dim3(512), 0, st, k);
         } else {
-            dim3 grid(ceil_div(k.Wg, 32) * ceil_div(k.Hg, 4) * k.N, co_tiles);
-            hipLaunchKernelGGL((conv_halo<T, 4, 1, 9>), grid, dim3(256), 0, st, k);
+            if (one_chunk) {
+                const int ntiles = ceil_div(k.Wg, 32) * ceil_div(k.Hg, 8) * k.N;
+                hipLaunchKernelGGL((conv_halo<T, 8, 1, 9, true>), dim3(ntiles < 256 ? ntiles : 256, co_tiles), dim3(512), 0, st, k);
+            } else {
+                const int ntiles = ceil_div(k.Wg, 32) * ceil_div(k.Hg, 4) * k.N;
+                hipLaunchKernelGGL((conv_halo<T, 4, 1, 9, false>), dim3(ntiles, co_tiles), dim3(256), 0, st, k);
+            }
         }
         BTS_LAUNCH_CHECK();
         return BTS_OK;
