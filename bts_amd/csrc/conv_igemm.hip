@@ -541,8 +541,9 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
     constexpr int NTHR = 64 * TH, RP = NTHR / 8;                // rows per DMA pass
     constexpr int VEC = T::kVec, ES = T::kBytes;
     constexpr int PR_PAD = (PR + RP - 1) / RP * RP;
+    constexpr int WR_PAD = (WR_ROWS + RP - 1) / RP * RP;
     constexpr int NPB = PERSIST ? 2 : 1;                        // patch buffers
-    __shared__ __attribute__((aligned(16))) char smem[(NPB * PR_PAD + WR_ROWS) * 128];
+    __shared__ __attribute__((aligned(16))) char smem[(NPB * PR_PAD + WR_PAD) * 128];
     char* sW = smem + NPB * PR_PAD * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -583,11 +584,11 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
         const int cv = cc * 8 + vec;
         const bool kok = cv < a.KV;
 #pragma unroll
-        for (int pass = 0; pass < WR_ROWS / RP; ++pass) {
+        for (int pass = 0; pass < WR_PAD / RP; ++pass) {
             const int r = pass * RP + srow;
             const int t = r >> 5, co = co_tile * 32 + (r & 31);
             const char* src = zero;
-            if (kok && co < a.Cout) src = a.w + (((size_t)co * a.Ttot + t) * a.Ktot + (size_t)cv * VEC) * ES;
+            if (kok && r < WR_ROWS && co < a.Cout) src = a.w + (((size_t)co * a.Ttot + t) * a.Ktot + (size_t)cv * VEC) * ES;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sW + (pass * RP + wave * 8) * 128), 16, 0, 0);
         }
     };
