@@ -42,6 +42,19 @@ class ConvDesc(C.Structure):
     ]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("cmap", C.c_void_p),
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("KK", C.c_int32), ("mode", C.c_int32),
+                ("R", C.c_int32), ("K", C.c_int32), ("T", C.c_int32),
+                ("tapmask", C.c_uint16 * MAX_TAP), ("pad_", C.c_int32)]
+
+
+class UnpackJob(C.Structure):
+    _fields_ = [("dwp_off", C.c_int64), ("gw_off", C.c_int64), ("kinv", C.c_void_p),
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("KK", C.c_int32), ("K", C.c_int32), ("T", C.c_int32),
+                ("tapmask", C.c_uint16 * MAX_TAP), ("pad_", C.c_int32)]
+
+
 _i, _l, _f, _p = C.c_int, C.c_long, C.c_float, C.c_void_p
 
 # name -> argtypes (restype is int unless listed in _LONG_RET); mirrors include/bts_amd.h exactly
@@ -62,6 +75,8 @@ SIGNATURES = {
     "bts_conv_wgrad": [C.POINTER(ConvDesc), _p, _i, _p, _p],
     "bts_pack_weight": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p, _p],
     "bts_unpack_wgrad": [_p, _i, _i, _i, _p, _i, _i, _p, _p, _i, _p],
+    "bts_pack_weight_batch": [_p, _i, _l, _i, _p],
+    "bts_unpack_wgrad_batch": [_p, _i, _l, _p, _p, _p],
     "bts_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "bts_nhwc_to_nchw": [_p, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     "bts_bn_stats_workspace_bytes": [_l, _i],

@@ -207,11 +207,10 @@ class ConvLayer:
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return gx
 
-    def wgrad(self, segs, dz):
-        """Returns the f32 weight gradient in PyTorch layout."""
+    def wgrad_packed(self, segs, dz, dwp):
+        """Accumulates the packed f32 weight gradient [Cout, nphase*T, Ktot] into `dwp` (caller-zeroed)."""
         dtype = segs[0].dtype
         N, Hx, Wx, _ = segs[0].shape
-        tb = self.tables(dtype, dz.device)
         d = self._desc(dtype, segs, N, Hx, Wx)
         d.isc = 1
         d.nphase, d.T = self.nphase, self.T
@@ -220,9 +219,15 @@ class ConvLayer:
         d.Cout = self.cout
         d.Hy, d.Wy = dz.shape[1], dz.shape[2]
         d.osc = 2 if self.up else 1
-        dwp = torch.zeros((self.cout, self.nphase * self.T, tb["ktot"]), dtype=torch.float32, device=dz.device)
         if profiler.ACTIVE is not None:
             profiler.note("conv_wgrad<%s,%s>" % (_dn(dtype), _wtile(self.cout)), "mfma",
                           2.0 * N * Hx * Wx * self.nphase * self.T * self.cin * self.cout)
         call("bts_conv_wgrad", C.byref(d), C.c_void_p(dz.data_ptr()), pix_stride(dz), C.c_void_p(dwp.data_ptr()), stream_ptr())
-        return self.unpack_wgrad(dwp, dtype)
+        return dwp
+
+    def wgrad(self, segs, dz):
+        """Returns the f32 weight gradient in PyTorch layout."""
+        tb = self.tables(segs[0].dtype, dz.device)
+        dwp = torch.zeros((self.cout, self.nphase * self.T, tb["ktot"]), dtype=torch.float32, device=dz.device)
+        self.wgrad_packed(segs, dz, dwp)
+        return self.unpack_wgrad(dwp, segs[0].dtype)

@@ -1019,6 +1019,46 @@ __global__ void unpack_wgrad_kernel(const PackK a) {
     }
 }
 
+// multi-tensor variants: one launch packs (unpacks) every layer of the decoder; the job table lives on the device
+template <typename T>
+__global__ void pack_weight_batch_kernel(const bts_pack_job_t* __restrict__ jobs) {
+    const bts_pack_job_t j = jobs[blockIdx.y];
+    const long total = (long)j.R * j.T * j.K;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % j.K);
+        const int t = (int)((idx / j.K) % j.T);
+        const int r = (int)(idx / ((long)j.K * j.T));
+        float v = 0.f;
+        int co, ci;
+        if (j.mode == 0) { co = r; ci = j.cmap[k]; }
+        else { co = k; ci = j.cmap[r]; }
+        if (ci >= 0 && co < j.Cout) {
+            const float* p = j.w + ((size_t)co * j.Cin + ci) * j.KK;
+            const uint32_t mask = j.tapmask[t];
+            for (int s = 0; s < j.KK; ++s) if (mask & (1u << s)) v += p[s];
+        }
+        T::st(j.out, idx, v);
+    }
+}
+
+__global__ void unpack_wgrad_batch_kernel(const bts_unpack_job_t* __restrict__ jobs, const float* __restrict__ dwp_base,
+                                          float* __restrict__ gw_base) {
+    const bts_unpack_job_t j = jobs[blockIdx.y];
+    const float* dwp = dwp_base + j.dwp_off;
+    float* gw = gw_base + j.gw_off;
+    const long total = (long)j.Cout * j.Cin * j.KK;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(idx % j.KK);
+        const int ci = (int)((idx / j.KK) % j.Cin);
+        const int co = (int)(idx / ((long)j.KK * j.Cin));
+        const int k = j.kinv[ci];
+        float v = 0.f;
+        for (int t = 0; t < j.T; ++t)
+            if (j.tapmask[t] & (1u << s)) v += dwp[((size_t)co * j.T + t) * j.K + k];
+        gw[idx] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1153,9 +1193,9 @@ template <typename T>
 static int launch_wgrad(const ConvK& k0, hipStream_t st) {
     ConvK k = k0;
     constexpr int PK = 8 * T::kVec;
-    auto go = [&](auto kern, int BM) {
+    auto go = [&](auto kern, int BM, int BN) {
         k.n_co_tiles = ceil_div(k.Cout, BM);
-        k.n_col_tiles = ceil_div((long)k.T * k.Ktot, 128);
+        k.n_col_tiles = ceil_div((long)k.T * k.Ktot, BN);
         k.nchunks = ceil_div(k.M, PK);
         const int tiles = k.n_co_tiles * k.n_col_tiles * k.nphase;
         int splits = ceil_div(1024, tiles);
@@ -1166,9 +1206,18 @@ static int launch_wgrad(const ConvK& k0, hipStream_t st) {
         dim3 grid(k.n_co_tiles * k.n_col_tiles, splits, k.nphase);
         hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, k);
     };
-    if (k.Cout > 64) go(conv_wgrad<T, 2, 2, 1, 2, 2>, 128);
-    else if (k.Cout > 32) go(conv_wgrad<T, 1, 2, 2, 2, 2>, 64);
-    else go(conv_wgrad<T, 1, 1, 4, 1, 4>, 32);
+    // tile by output shape [Cout x (taps*K)]: narrow column tiles for the tiny 1x1 layers of the reduction chains keep
+    // the register count low (these launches are latency-bound: occupancy is what matters, r1 profile)
+    const long cols = (long)k.T * k.Ktot;
+    if (k.Cout > 64) go(conv_wgrad<T, 2, 2, 1, 2, 2>, 128, 128);
+    else if (k.Cout > 32) {
+        if (cols <= 64) go(conv_wgrad<T, 1, 1, 4, 2, 2>, 64, 64);
+        else go(conv_wgrad<T, 1, 2, 2, 2, 2>, 64, 128);
+    } else {
+        if (cols <= 32) go(conv_wgrad<T, 1, 1, 4, 1, 1>, 32, 32);
+        else if (cols <= 64) go(conv_wgrad<T, 1, 1, 4, 1, 2>, 32, 64);
+        else go(conv_wgrad<T, 1, 1, 4, 1, 4>, 32, 128);
+    }
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }
@@ -1239,6 +1288,27 @@ extern "C" int bts_unpack_wgrad(const float* dwp, int Cout, int Cin, int KK, con
     const long total = (long)Cout * Cin * KK;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_pack_weight_batch(const bts_pack_job_t* jobs, int n_jobs, long max_elems, int dtype, bts_stream_t stream) {
+    BTS_CHECK_ARG(jobs && n_jobs > 0 && max_elems > 0 && (dtype == BTS_F32 || dtype == BTS_BF16));
+    long bx = (max_elems + 256 * 4 - 1) / (256 * 4);
+    if (bx > 256) bx = 256;
+    dim3 grid((unsigned)bx, (unsigned)n_jobs);
+    if (dtype == BTS_F32) hipLaunchKernelGGL(pack_weight_batch_kernel<F32>, grid, dim3(256), 0, (hipStream_t)stream, jobs);
+    else hipLaunchKernelGGL(pack_weight_batch_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, jobs);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_unpack_wgrad_batch(const bts_unpack_job_t* jobs, int n_jobs, long max_elems, const float* dwp_base,
+                                      float* gw_base, bts_stream_t stream) {
+    BTS_CHECK_ARG(jobs && n_jobs > 0 && max_elems > 0 && dwp_base && gw_base);
+    long bx = (max_elems + 256 * 4 - 1) / (256 * 4);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(unpack_wgrad_batch_kernel, dim3((unsigned)bx, (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream, jobs, dwp_base, gw_base);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }

@@ -116,8 +116,20 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double a = 0, b = 0;
-    if (c < C)
-        for (int k = pl; k < nparts; k += 8) { a += ws[((size_t)k * 2 + 0) * Cpad + c]; b += ws[((size_t)k * 2 + 1) * Cpad + c]; }
+    if (c < C) {
+        // 4 independent accumulator pairs: the loop is latency-bound (each block owns only 32 channels)
+        double a1 = 0, b1 = 0, a2 = 0, b2 = 0, a3 = 0, b3 = 0;
+        int k = pl;
+        for (; k + 24 < nparts; k += 32) {
+            a += ws[((size_t)k * 2 + 0) * Cpad + c];          b += ws[((size_t)k * 2 + 1) * Cpad + c];
+            a1 += ws[((size_t)(k + 8) * 2 + 0) * Cpad + c];   b1 += ws[((size_t)(k + 8) * 2 + 1) * Cpad + c];
+            a2 += ws[((size_t)(k + 16) * 2 + 0) * Cpad + c];  b2 += ws[((size_t)(k + 16) * 2 + 1) * Cpad + c];
+            a3 += ws[((size_t)(k + 24) * 2 + 0) * Cpad + c];  b3 += ws[((size_t)(k + 24) * 2 + 1) * Cpad + c];
+        }
+        for (; k < nparts; k += 8) { a += ws[((size_t)k * 2 + 0) * Cpad + c]; b += ws[((size_t)k * 2 + 1) * Cpad + c]; }
+        a += a1 + a2 + a3;
+        b += b1 + b2 + b3;
+    }
     __shared__ double sa[8][33], sb[8][33];
     sa[pl][cl] = a; sb[pl][cl] = b;
     __syncthreads();

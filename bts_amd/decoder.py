@@ -11,8 +11,11 @@ Activations are NHWC in ``dtype`` (f32 for parity, bf16 for throughput); paramet
 statistics, LPG heads and the five outputs are f32.  torch.cat never happens: every conv reads
 its concatenated input as a list of segments.
 """
+import ctypes as C
+
 import torch
 
+from . import _lib
 from . import chain as chain_mod
 from . import ops
 from ._lib import ACT_ELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BtsAmdError
@@ -87,6 +90,79 @@ class DecoderPlan:
         add("get_depth.0", 1, [nf // 16], 9)
         self.layers = L
         self.chain_cache = {}
+        self.pack_cache = {}
+
+
+class PackSet:
+    """Packed operands of EVERY conv of the decoder for one (dtype, device): persistent output buffers plus
+    device-resident job tables, so a step issues one `bts_pack_weight_batch` for the forward operands, one for the
+    data-gradient operands, and one `bts_unpack_wgrad_batch` for all weight gradients (instead of ~170 tiny launches)."""
+
+    def __init__(self, plan, P, dtype):
+        self.dtype = dtype
+        names = list(plan.layers)
+        dev = P[names[0] + ".weight"].device
+        self.key = (dtype, tuple(P[n + ".weight"].data_ptr() for n in names))
+        self.fwd, self.dgrad = {}, {}
+        self.dwp_off, self.gw_off = {}, {}
+        fjobs, djobs, ujobs = [], [], []
+        self.fmax = self.dmax = self.umax = 1
+        dwp_total = gw_total = 0
+        for n in names:
+            L = plan.layers[n]
+            w = P[n + ".weight"]
+            tb = L.tables(dtype, dev)
+            ttot = L.nphase * L.T
+            out = torch.empty((L.cout, ttot, tb["ktot"]), dtype=dtype, device=dev)
+            self.fwd[n] = out
+            fjobs.append(self._pjob(w, out, tb["cmap"], L, 0, L.cout, tb["ktot"], ttot))
+            self.fmax = max(self.fmax, out.numel())
+            for i, rows in enumerate(tb["seg_rows"]):
+                o = torch.empty((rows.numel(), ttot, tb["cout_pad"]), dtype=dtype, device=dev)
+                self.dgrad[(n, i)] = o
+                djobs.append(self._pjob(w, o, rows, L, 1, rows.numel(), tb["cout_pad"], ttot))
+                self.dmax = max(self.dmax, o.numel())
+            self.dwp_off[n] = (dwp_total, (L.cout, ttot, tb["ktot"]))
+            self.gw_off[n] = (gw_total, tuple(w.shape))
+            uj = _lib.UnpackJob()
+            uj.dwp_off, uj.gw_off, uj.kinv = dwp_total, gw_total, tb["kinv"].data_ptr()
+            uj.Cout, uj.Cin, uj.KK, uj.K, uj.T = L.cout, L.cin, L.kk, tb["ktot"], ttot
+            for t, m in enumerate(L.masks):
+                uj.tapmask[t] = m
+            ujobs.append(uj)
+            self.umax = max(self.umax, w.numel())
+            dwp_total += L.cout * ttot * tb["ktot"]
+            gw_total += w.numel()
+        self.dwp_total, self.gw_total = dwp_total, gw_total
+        self.fjobs, self.nf = self._upload(fjobs, dev), len(fjobs)
+        self.djobs, self.nd = self._upload(djobs, dev), len(djobs)
+        self.ujobs, self.nu = self._upload(ujobs, dev), len(ujobs)
+
+    @staticmethod
+    def _pjob(w, out, cmap, L, mode, R, K, ttot):
+        j = _lib.PackJob()
+        j.w, j.out, j.cmap = w.data_ptr(), out.data_ptr(), cmap.data_ptr()
+        j.Cout, j.Cin, j.KK, j.mode, j.R, j.K, j.T = L.cout, L.cin, L.kk, mode, R, K, ttot
+        for t, m in enumerate(L.masks):
+            j.tapmask[t] = m
+        return j
+
+    @staticmethod
+    def _upload(jobs, dev):
+        raw = b"".join(bytes(j) for j in jobs)
+        return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+
+    def pack_forward(self):
+        _lib.call("bts_pack_weight_batch", C.c_void_p(self.fjobs.data_ptr()), self.nf, self.fmax, _lib.dtype_code(self.dtype),
+                  _lib.stream_ptr())
+
+    def pack_dgrad(self):
+        _lib.call("bts_pack_weight_batch", C.c_void_p(self.djobs.data_ptr()), self.nd, self.dmax, _lib.dtype_code(self.dtype),
+                  _lib.stream_ptr())
+
+    def unpack_all(self, dwp_arena, gw_arena):
+        _lib.call("bts_unpack_wgrad_batch", C.c_void_p(self.ujobs.data_ptr()), self.nu, self.umax,
+                  C.c_void_p(dwp_arena.data_ptr()), C.c_void_p(gw_arena.data_ptr()), _lib.stream_ptr())
 
 
 class DecoderRun:
@@ -99,6 +175,14 @@ class DecoderRun:
         self.tape, self.grads = [], {}
         self.feat_acts, self.feat_src = [], []
         self.outs = None
+        names = list(plan.layers)
+        key = (dtype, tuple(P[n + ".weight"].data_ptr() for n in names))
+        ps = plan.pack_cache.get(dtype)
+        if ps is None or ps.key != key:
+            ps = PackSet(plan, P, dtype)
+            plan.pack_cache[dtype] = ps
+        self.packs = ps
+        self.dwp_arena = None
 
     # ---- ops -------------------------------------------------------------------------------
     def feature(self, f, relu=False):
@@ -112,8 +196,7 @@ class DecoderRun:
 
     def conv(self, name, segs, act, out_map=False, out_f32=False, out_scale=1.0, out_scale_n=None):
         L = self.plan.layers[name]
-        w = self.P[name + ".weight"]
-        wp = L.pack_fwd(w, self.dtype)
+        wp = self.packs.fwd[name]
         x = [s.t for s in segs]
         N, Hx, Wx, _ = x[0].shape
         Ho, Wo = (2 * Hx, 2 * Wx) if L.up else (Hx, Wx)
@@ -138,12 +221,13 @@ class DecoderRun:
                 else:
                     dz = ops.act_bwd(y.g, y.t, act, out=y.g)
                 for i, s in enumerate(segs):
-                    wd = L.pack_dgrad(w, self.dtype, i)
                     acc = s.g is not None
                     if not acc:
                         s.g = torch.empty(s.t.shape, dtype=self.dtype, device=dev)
-                    L.dgrad(dz, wd, i, s.g, acc)
-                self.grads[name + ".weight"] = L.wgrad(x, dz)
+                    L.dgrad(dz, self.packs.dgrad[(name, i)], i, s.g, acc)
+                off, shape = self.packs.dwp_off[name]
+                n_el = shape[0] * shape[1] * shape[2]
+                L.wgrad_packed(x, dz, self.dwp_arena[off:off + n_el].view(shape))
             self.tape.append(bwd)
         return y
 
@@ -283,6 +367,7 @@ class DecoderRun:
     # ---- schedule (bts.forward, bts.py:196-266) ------------------------------------------------
     def forward(self, features, focal):
         f = features
+        self.packs.pack_forward()
         N, _, H2, W2 = f[0].shape
         H, W = 2 * H2, 2 * W2
         s0, s1, s2, s3 = (self.feature(f[i]) for i in range(4))
@@ -324,9 +409,20 @@ class DecoderRun:
             if g is not None:
                 # the LPG maps also receive gradient through conv1/conv3/conv2: own the buffer
                 o.g = g.reshape(o.t.shape).to(torch.float32).clone(memory_format=torch.contiguous_format)
+        dev = self.outs[0].t.device
+        self.packs.pack_dgrad()
+        self.dwp_arena = torch.zeros(self.packs.dwp_total, dtype=torch.float32, device=dev)     # one memset for every layer
         for fn in reversed(self.tape):
             fn()
         self.tape = []
+        gw_arena = torch.empty(self.packs.gw_total, dtype=torch.float32, device=dev)
+        self.packs.unpack_all(self.dwp_arena, gw_arena)
+        for name, (off, shape) in self.packs.gw_off.items():
+            n_el = 1
+            for d in shape:
+                n_el *= d
+            self.grads[name + ".weight"] = gw_arena[off:off + n_el].view(shape)
+        self.dwp_arena = None
         gfeats = []
         for a, (relu_src, Cc) in zip(self.feat_acts, self.feat_src):
             gfeats.append(None if a.g is None else ops.nhwc_to_nchw(a.g, Cc, relu_src))

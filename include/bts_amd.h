@@ -190,6 +190,25 @@ int bts_pack_weight(const float* w, int Cout, int Cin, int KK, int mode, const i
 int bts_unpack_wgrad(const float* dwp, int Cout, int Cin, int KK, const int32_t* kinv, int K, int T,
                      const uint16_t* tapmask, float* gw, int accumulate, bts_stream_t stream);
 
+/* Multi-tensor forms of the two functions above: ONE launch for every layer of the decoder (the eager path would
+ * otherwise issue ~130 tiny launches per step).  The job tables live on the DEVICE; field meanings as above. */
+typedef struct {
+    const float* w; void* out; const int32_t* cmap;
+    int32_t Cout, Cin, KK, mode, R, K, T;
+    uint16_t tapmask[BTS_MAX_TAP];
+    int32_t pad_;
+} bts_pack_job_t;
+typedef struct {
+    int64_t dwp_off; int64_t gw_off;   /* element offsets into the dwp / gw arenas passed to the call */
+    const int32_t* kinv;
+    int32_t Cout, Cin, KK, K, T;
+    uint16_t tapmask[BTS_MAX_TAP];
+    int32_t pad_;
+} bts_unpack_job_t;
+int bts_pack_weight_batch(const bts_pack_job_t* jobs, int n_jobs, long max_elems, int dtype, bts_stream_t stream);
+int bts_unpack_wgrad_batch(const bts_unpack_job_t* jobs, int n_jobs, long max_elems, const float* dwp_base,
+                           float* gw_base, bts_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Elementwise / normalisation kernels (HBM-bound)
  * ---------------------------------------------------------------------------------- */
