@@ -234,8 +234,10 @@ def main():
     net = model
     reducer = None
     if world > 1 and args.reducer == "ddp":
+        # ResNet-family backbones carry the unused torchvision head (avgpool/fc): bts_main.py:352 sets find_unused_parameters
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
-                                                        broadcast_buffers=False)
+                                                        broadcast_buffers=False,
+                                                        find_unused_parameters="resne" in args.encoder)
     elif world > 1:
         from bts_amd.parallel import GradAllReducer, broadcast_parameters
         broadcast_parameters(model)
@@ -357,7 +359,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         out = {
-            "metric": "images/sec (train step) DenseNet161-BTS 352x1216",
+            "metric": "images/sec (train step) DenseNet161-BTS 352x1216" if (args.encoder, args.height, args.width) == ("densenet161_bts", 352, 1216) else "images/sec (train step) %s %dx%d" % (args.encoder, args.height, args.width),
             "value": round(args.batch * world * args.steps / elapsed, 3),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -235,3 +235,35 @@ def test_fused_inference_chain_matches_layerwise(nf, feat, dt, tol):
         ref, _ = O.decoder_forward(P, feats, focal, 80.0, "kitti", False)
         for a, r in zip(fused, ref):
             assert rel(a, r) < 1e-4
+
+
+@pytest.mark.parametrize("enc", ["densenet121_bts", "resnet50_bts"])
+def test_full_model_bf16_autocast_train_step(enc):
+    """Throughput configuration: encoder under bf16 autocast (bf16 NCHW features into the decoder), bf16 decoder,
+    f32 master weights; one train step must produce finite loss / gradients and change the weights."""
+    from bts_amd.model import BtsModel, silog_loss, weights_init_xavier
+    from bts_amd.optim import FusedAdamW
+    params = NS(encoder=enc, max_depth=80.0, dataset="kitti", bts_size=512, decoder_dtype=torch.bfloat16)
+    torch.manual_seed(3)
+    model = BtsModel(params)
+    model.decoder.apply(weights_init_xavier)
+    model.train().to(DEV)
+    gen = torch.Generator().manual_seed(4)
+    B, H, W = 2, 96, 128
+    x = torch.randn(B, 3, H, W, generator=gen).to(DEV)
+    focal = O.synth_focal(B, "kitti").to(DEV)
+    gt = O.synth_depth_gt(B, H, W, "kitti", gen).to(DEV)
+    opt = FusedAdamW([{"params": list(model.encoder.parameters()), "weight_decay": 1e-2},
+                      {"params": list(model.decoder.parameters()), "weight_decay": 0.0}], lr=1e-4, eps=1e-3)
+    w0 = model.decoder.conv1[0].weight.detach().clone()
+    for _ in range(2):
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            outs = model(x, focal)
+        assert all(o.dtype == torch.float32 for o in outs)
+        loss = silog_loss(0.85)(outs[4], gt, gt > 1.0)
+        loss.backward()
+        opt.step()
+    assert torch.isfinite(loss)
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in model.parameters())
+    assert not torch.equal(w0, model.decoder.conv1[0].weight)
