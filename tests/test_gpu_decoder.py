@@ -267,3 +267,25 @@ def test_full_model_bf16_autocast_train_step(enc):
     assert torch.isfinite(loss)
     assert all(p.grad is None or torch.isfinite(p.grad).all() for p in model.parameters())
     assert not torch.equal(w0, model.decoder.conv1[0].weight)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 96, 160), (3, 32, 64), (1, 416, 544)])
+def test_decoder_ragged_shapes_vs_oracle(B, H, W):
+    """Odd grid sizes (H/32 x W/32 = 3x5, 1x2, 13x17 = BASELINE configs[0/1] 416x544), batch sizes that are not powers of
+    two: tile tails of every kernel (pixel tiles, halo tiles, LPG rows) against the CPU oracle, f32, eval + train."""
+    feat, nf = [8, 8, 16, 24, 40], 128
+    gen = torch.Generator().manual_seed(B * 1000 + H)
+    P = O.make_decoder_params(feat, nf, gen, randomize_bn=True)
+    feats = O.make_features(feat, B, H, W, gen)
+    focal = O.synth_focal(B, "nyu")
+    for train in (False, True):
+        ref, _ = O.decoder_forward(P, feats, focal, 10.0, "nyu", train)
+        dec, _ = build(feat, nf, "nyu", P, train=train)
+        outs = dec([f.to(DEV).requires_grad_(True) for f in feats], focal.to(DEV))
+        for o, r in zip(outs, ref):
+            assert tuple(o.shape) == (B, 1, H, W)
+            assert rel(o, r) < 1e-4
+        with torch.no_grad():
+            outs2 = dec([f.to(DEV) for f in feats], focal.to(DEV))      # fused no-grad heads
+        for o, r in zip(outs2, ref):
+            assert rel(o, r) < 1e-4
