@@ -77,8 +77,8 @@ SIGNATURES = {
     "bts_unpack_wgrad": [_p, _i, _i, _i, _p, _i, _i, _p, _p, _i, _p],
     "bts_pack_weight_batch": [_p, _i, _l, _i, _p],
     "bts_unpack_wgrad_batch": [_p, _i, _l, _p, _p, _p],
-    "bts_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
-    "bts_nhwc_to_nchw": [_p, _i, _i, _p, _p, _i, _i, _i, _i, _p],
+    "bts_nchw_to_nhwc": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "bts_nhwc_to_nchw": [_p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p],
     "bts_bn_stats_workspace_bytes": [_l, _i],
     "bts_bn_stats": [_p, _i, _i, _l, _i, _p, _p, _p, _p],
     "bts_bn_prepare": [_p, _p, _i, _l, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p],

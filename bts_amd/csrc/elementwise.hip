@@ -311,9 +311,9 @@ __global__ __launch_bounds__(256) void add_to_kernel(const void* __restrict__ x,
     }
 }
 
-// ---- NCHW f32 <-> NHWC -------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restrict__ dst, int ds,
+// ---- NCHW (f32 / bf16) <-> NHWC -----------------------------------------------------------------
+template <typename TS, typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const void* __restrict__ src, void* __restrict__ dst, int ds,
                                                            int C, int HW, int relu) {
     __shared__ float tile[32][33];
     const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     for (int k = ty; k < 32; k += 8) {
         const int c = c0 + k, p = p0 + tx;
         float v = 0.f;
-        if (c < C && p < HW) v = src[((size_t)n * C + c) * HW + p];
+        if (c < C && p < HW) v = TS::ld(src, ((size_t)n * C + c) * HW + p);
         if (relu) v = fmaxf(v, 0.f);
         tile[k][tx] = v;
     }
@@ -332,9 +332,9 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restrict__ src, int ss, float* __restrict__ dst,
-                                                           const float* __restrict__ relu_src, int C, int HW) {
+template <typename T, typename TD>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restrict__ src, int ss, void* __restrict__ dst,
+                                                           const void* __restrict__ relu_src, int C, int HW) {
     __shared__ float tile[32][33];
     const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -350,8 +350,8 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restric
         if (c < C && p < HW) {
             const size_t o = ((size_t)n * C + c) * HW + p;
             float v = tile[tx][k];
-            if (relu_src && !(relu_src[o] > 0.f)) v = 0.f;
-            dst[o] = v;
+            if (relu_src && !(TD::ld(relu_src, o) > 0.f)) v = 0.f;
+            TD::st(dst, o, v);
         }
     }
 }
@@ -543,26 +543,32 @@ extern "C" int bts_add_to(const void* x, int x_dtype, int x_stride, void* y, int
     return BTS_OK;
 }
 
-extern "C" int bts_nchw_to_nhwc(const float* src, void* dst, int dst_dtype, int dst_stride, int N, int C, int H, int W, int relu,
-                                bts_stream_t stream) {
+extern "C" int bts_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int dst_stride, int N, int C, int H,
+                                int W, int relu, bts_stream_t stream) {
     BTS_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && dst_stride >= C);
-    BTS_CHECK_ARG(dst_dtype == BTS_F32 || dst_dtype == BTS_BF16);
+    BTS_CHECK_ARG((dst_dtype == BTS_F32 || dst_dtype == BTS_BF16) && (src_dtype == BTS_F32 || src_dtype == BTS_BF16));
     const int HW = H * W;
     dim3 grid(ceil_div(HW, 32), ceil_div(C, 32), N);
-    if (dst_dtype == BTS_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<F32>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, dst_stride, C, HW, relu);
-    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, dst_stride, C, HW, relu);
+    hipStream_t st = (hipStream_t)stream;
+#define L_(A, B) hipLaunchKernelGGL((nchw_to_nhwc_kernel<A, B>), grid, dim3(256), 0, st, src, dst, dst_stride, C, HW, relu)
+    if (src_dtype == BTS_F32) { if (dst_dtype == BTS_F32) L_(F32, F32); else L_(F32, BF16); }
+    else { if (dst_dtype == BTS_F32) L_(BF16, F32); else L_(BF16, BF16); }
+#undef L_
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }
 
-extern "C" int bts_nhwc_to_nchw(const void* src, int src_dtype, int src_stride, float* dst, const float* relu_src, int N, int C,
-                                int H, int W, bts_stream_t stream) {
+extern "C" int bts_nhwc_to_nchw(const void* src, int src_dtype, int src_stride, void* dst, int dst_dtype, const void* relu_src,
+                                int N, int C, int H, int W, bts_stream_t stream) {
     BTS_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && src_stride >= C);
-    BTS_CHECK_ARG(src_dtype == BTS_F32 || src_dtype == BTS_BF16);
+    BTS_CHECK_ARG((src_dtype == BTS_F32 || src_dtype == BTS_BF16) && (dst_dtype == BTS_F32 || dst_dtype == BTS_BF16));
     const int HW = H * W;
     dim3 grid(ceil_div(HW, 32), ceil_div(C, 32), N);
-    if (src_dtype == BTS_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<F32>, grid, dim3(256), 0, (hipStream_t)stream, src, src_stride, dst, relu_src, C, HW);
-    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, src, src_stride, dst, relu_src, C, HW);
+    hipStream_t st = (hipStream_t)stream;
+#define L_(A, B) hipLaunchKernelGGL((nhwc_to_nchw_kernel<A, B>), grid, dim3(256), 0, st, src, src_stride, dst, relu_src, C, HW)
+    if (src_dtype == BTS_F32) { if (dst_dtype == BTS_F32) L_(F32, F32); else L_(F32, BF16); }
+    else { if (dst_dtype == BTS_F32) L_(BF16, F32); else L_(BF16, BF16); }
+#undef L_
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }

@@ -186,12 +186,15 @@ class DecoderRun:
 
     # ---- ops -------------------------------------------------------------------------------
     def feature(self, f, relu=False):
+        """Encoder feature (NCHW, f32 or bf16 under autocast) -> NHWC activation; no intermediate casts."""
         src = f.detach()
-        if src.dtype != torch.float32 or not src.is_contiguous():
-            src = src.float().contiguous()
+        if src.dtype not in (torch.float32, torch.bfloat16):
+            src = src.float()
+        if not src.is_contiguous():
+            src = src.contiguous()
         a = Act(ops.nchw_to_nhwc(src, self.dtype, relu))
         self.feat_acts.append(a)
-        self.feat_src.append((src if relu else None, f.shape[1]))
+        self.feat_src.append((src if relu else None, f.shape[1], src.dtype))
         return a
 
     def conv(self, name, segs, act, out_map=False, out_f32=False, out_scale=1.0, out_scale_n=None):
@@ -424,7 +427,7 @@ class DecoderRun:
             self.grads[name + ".weight"] = gw_arena[off:off + n_el].view(shape)
         self.dwp_arena = None
         gfeats = []
-        for a, (relu_src, Cc) in zip(self.feat_acts, self.feat_src):
-            gfeats.append(None if a.g is None else ops.nhwc_to_nchw(a.g, Cc, relu_src))
+        for a, (relu_src, Cc, sdt) in zip(self.feat_acts, self.feat_src):
+            gfeats.append(None if a.g is None else ops.nhwc_to_nchw(a.g, Cc, relu_src, out_dtype=sdt))
         # feature() was called for skips 0..3 then the dense map
         return gfeats, self.grads

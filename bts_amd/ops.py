@@ -128,19 +128,20 @@ def silog_bwd(est, gt, mask, variance_focus, stats, loss, grad_loss, gt_threshol
 # layout / elementwise / BN
 # ---------------------------------------------------------------------------------------------
 def nchw_to_nhwc(src, dtype, relu=False, c_pad=None):
-    """src f32 [N,C,H,W] contiguous -> NHWC [N,H,W,c_pad or C] in `dtype` (pad channels zero)."""
+    """src f32/bf16 [N,C,H,W] contiguous -> NHWC [N,H,W,c_pad or C] in `dtype` (pad channels zero)."""
     _lib.require_gpu(src)
     N, Cc, H, W = src.shape
     Cp = c_pad or Cc
     dst = (torch.zeros if Cp != Cc else torch.empty)((N, H, W, Cp), dtype=dtype, device=src.device)
-    call("bts_nchw_to_nhwc", _p(src), _p(dst), dtype_code(dtype), Cp, N, Cc, H, W, int(relu), stream_ptr())
+    call("bts_nchw_to_nhwc", _p(src), dtype_code(src.dtype), _p(dst), dtype_code(dtype), Cp, N, Cc, H, W, int(relu), stream_ptr())
     return dst
 
 
-def nhwc_to_nchw(src, Cc, relu_src=None):
+def nhwc_to_nchw(src, Cc, relu_src=None, out_dtype=torch.float32):
     N, H, W, _ = src.shape
-    dst = torch.empty((N, Cc, H, W), dtype=torch.float32, device=src.device)
-    call("bts_nhwc_to_nchw", _p(src), dtype_code(src.dtype), pix_stride(src), _p(dst), _p(relu_src), N, Cc, H, W, stream_ptr())
+    dst = torch.empty((N, Cc, H, W), dtype=out_dtype, device=src.device)
+    call("bts_nhwc_to_nchw", _p(src), dtype_code(src.dtype), pix_stride(src), _p(dst), dtype_code(out_dtype), _p(relu_src),
+         N, Cc, H, W, stream_ptr())
     return dst
 
 

@@ -212,11 +212,13 @@ int bts_unpack_wgrad_batch(const bts_unpack_job_t* jobs, int n_jobs, long max_el
 /* ------------------------------------------------------------------------------------
  * Elementwise / normalisation kernels (HBM-bound)
  * ---------------------------------------------------------------------------------- */
-/* NCHW f32 -> NHWC (dtype), optional ReLU (bts.py:198): dst[n][h][w][c] at dst_stride. */
-int bts_nchw_to_nhwc(const float* src, void* dst, int dst_dtype, int dst_stride, int N, int C, int H, int W,
+/* Encoder boundary.  NCHW (f32 or bf16: what a stock PyTorch encoder emits, bf16 under autocast) -> NHWC (dst_dtype),
+ * optional ReLU (bts.py:198): dst[n][h][w][c] at dst_stride. */
+int bts_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int dst_stride, int N, int C, int H, int W,
                      int relu, bts_stream_t stream);
-/* NHWC (dtype) gradient -> NCHW f32; if relu_src != NULL (the NCHW forward input) multiplies by (src > 0). */
-int bts_nhwc_to_nchw(const void* src, int src_dtype, int src_stride, float* dst, const float* relu_src,
+/* NHWC gradient -> NCHW (dst_dtype, = the dtype autograd expects for that feature); if relu_src != NULL (the NCHW forward
+ * input, same dtype as dst) the gradient is multiplied by (relu_src > 0). */
+int bts_nhwc_to_nchw(const void* src, int src_dtype, int src_stride, void* dst, int dst_dtype, const void* relu_src,
                      int N, int C, int H, int W, bts_stream_t stream);
 
 /* Per-channel batch statistics of an NHWC tensor over M = N*H*W pixels (train-mode BatchNorm,

@@ -242,6 +242,8 @@ def test_layout_roundtrip_and_pack_maps():
         t = ops.nchw_to_nhwc(x.to(DEV), dt, relu=True)
         assert rel(t.float().permute(0, 3, 1, 2), F.relu(x)) <= tol
         back = ops.nhwc_to_nchw(t, 24, relu_src=x.to(DEV))
+        tb = ops.nchw_to_nhwc(x.to(DEV).to(torch.bfloat16), dt, relu=True)        # bf16 source (autocast encoder)
+        assert rel(tb.float().permute(0, 3, 1, 2), F.relu(x)) <= 8e-3
         assert rel(back, F.relu(x)) <= tol
     d8 = torch.randn(2, 16, 24, generator=gen).to(DEV)
     slot = ops.pack_maps([d8], [4], 2, 4, 6, torch.float32)
