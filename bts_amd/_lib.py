@@ -66,6 +66,7 @@ SIGNATURES = {
     "bts_lpg_head_fwd": [_p, _i, _p, _p, _i, _i, _i, _i, _f, _p],
     "bts_lpg_head_bwd": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "bts_lpg_chain_fwd": [_p, _i, _i, _i, _i, _p, _i, _p, _l, _i, _i, _i, _f, _p],
+    "bts_lpg_chain_bwd": [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _l, _i, _i, _i, _f, _p],
     "bts_pack_maps": [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "bts_unpack_maps": [_p, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     "bts_silog_workspace_bytes": [_l],

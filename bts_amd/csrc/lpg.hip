@@ -11,10 +11,10 @@
 // own (__fmul_rn/__fadd_rn, no FMA contraction), followed by IEEE division -- the reference's
 // exact operation order, so the LPG op is bit-identical to the PyTorch CPU path.
 #include "common.h"
+#include "lpg_math.h"
 
 namespace {
 
-__device__ __forceinline__ float lpg_offset(int r, int k) { return ((float)r - (float)(k - 1) * 0.5f) / (float)k; }
 
 __device__ __forceinline__ float lpg_eval(float n1, float n2, float n3, float n4, float u, float v, float div) {
     const float den = __fadd_rn(__fadd_rn(__fmul_rn(n1, u), __fmul_rn(n2, v)), n3);
@@ -91,29 +91,6 @@ __global__ __launch_bounds__(256) void lpg_bwd_kernel(const float* __restrict__ 
 }
 
 // ---- fused head ------------------------------------------------------------------------------
-struct Plane {
-    float n1, n2, n3, n4;        // normalised plane
-    float s0, s1, s2;            // sigmoids
-    float st, ct, sp, cp;        // sin/cos theta, phi
-    float m1, m2, m3, inv_norm;  // un-normalised normal and 1/max(norm, 1e-12)
-};
-
-__device__ __forceinline__ Plane plane_from_raw(float r0, float r1, float r2, float max_depth) {
-    Plane p;
-    p.s0 = act_sigmoid(r0); p.s1 = act_sigmoid(r1); p.s2 = act_sigmoid(r2);
-    const float theta = __fdiv_rn(__fmul_rn(p.s0, 3.14159274101257324f), 3.0f);   // sigmoid * math.pi / 3 (bts.py:113)
-    const float phi = __fmul_rn(__fmul_rn(p.s1, 3.14159274101257324f), 2.0f);     // sigmoid * math.pi * 2 (bts.py:114)
-    sincosf(theta, &p.st, &p.ct);
-    sincosf(phi, &p.sp, &p.cp);
-    p.m1 = __fmul_rn(p.st, p.cp); p.m2 = __fmul_rn(p.st, p.sp); p.m3 = p.ct;     // bts.py:116-118
-    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(p.m1, p.m1), __fmul_rn(p.m2, p.m2)), __fmul_rn(p.m3, p.m3)));
-    const float d = fmaxf(nrm, 1e-12f);                                           // F.normalize eps (bts.py:224)
-    p.inv_norm = 1.f / d;
-    p.n1 = p.m1 / d; p.n2 = p.m2 / d; p.n3 = p.m3 / d;
-    p.n4 = __fmul_rn(p.s2, max_depth);                                            // bts.py:115
-    return p;
-}
-
 // forward: RPT patch rows per thread.  k = 8 uses one thread per (cell, row) -- 8x more threads than cells,
 // so even B*h*w = 53 k cells (352x1216, batch 8) fill all 256 CUs; k = 4 / 2 use one thread per cell
 // (all k rows), which keeps the transcendental work (sigmoid x3, sincos x2, normalise) at once per cell --

@@ -20,6 +20,7 @@
 // A wave owns 32 consecutive cells per iteration; lanes 32-63 take the lower half of each cell's k x k patch rows
 // in the LPG epilogue (plane parameters forwarded by a DPP-free __shfl), so stores are 64 lanes wide.
 #include "common.h"
+#include "lpg_math.h"
 
 namespace {
 
@@ -268,6 +269,311 @@ int dispatch_chain(const ChainK& k, int c0, int same_first, int kup, hipStream_t
     return BTS_ERR_UNSUPPORTED;
 }
 
+
+// ---- training: recompute backward of a halving chain (C0 <= 64, bf16) ------------------------------------------
+// One pass per tile of 32 cells per wave: the forward chain is recomputed from x (no activation of the chain is ever
+// stored), the head is differentiated in registers, and the gradient walks back through the layers with the same
+// register chaining as the forward (dA = W^T dz: the accumulator of one MFMA is the B operand of the next).  The weight
+// gradients dW_l = dz_l a_l^T contract over CELLS, the one index MFMA operands do not hold contiguously, so dz_l and
+// a_l are transposed through a per-wave LDS scratch (ds_write_b16 rows [channel][32 cells], read back as 16-byte
+// fragments) and accumulated in registers over every tile the wave owns; one cross-wave LDS reduction and one set of
+// atomics per workgroup at the end.  HBM traffic: x once, grad_out once, dx once (+ read when accumulating).
+constexpr int RS = 80;   // scratch row stride in bytes: 32 cells * 2 B + 16 B skew
+
+template <int C, int NOUT>
+constexpr int bwd_scr_rows() {
+    constexpr int cout = C > 8 ? C / 2 : NOUT;
+    int rows = 32 * ((cout + 31) / 32) + 32 * ((C + 31) / 32);
+    if constexpr (C > 8) rows += bwd_scr_rows<C / 2, NOUT>();
+    return rows;
+}
+template <int C, int NOUT>
+constexpr int bwd_dw_tiles() {
+    constexpr int cout = C > 8 ? C / 2 : NOUT;
+    int n = ((cout + 31) / 32) * ((C + 31) / 32);
+    if constexpr (C > 8) n += bwd_dw_tiles<C / 2, NOUT>();
+    return n;
+}
+
+struct ChainBwdK {
+    const void* x;
+    int x_stride;
+    const char* wf;     // forward A fragments (same buffer as the forward kernel's)
+    int wf_bytes;
+    const char* wt;     // A fragments of W^T per layer (rows = input channels, K = output channels, accumulator K order)
+    int wt_bytes;
+    const float* gout;  // grad of depth [B][h*k][w*k] (k > 1) or of the sigmoid map [cells] (k = 1)
+    void* dx;
+    int dx_stride, dx_accumulate;
+    float* dw[6];       // per layer: packed f32 weight gradient [Cout][ld], accumulated atomically
+    int dw_ld[6];
+    long cells;
+    int h, w_cells;
+    float max_depth;
+};
+
+struct TileCtx {
+    const float* gout;
+    long cell;
+    bool ok;
+    int w_cells, lane, cl, g;
+    float max_depth;
+};
+
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }   // d elu(z)/dz given y = elu(z)
+
+// rows[channel][cell] <- register image (NATURAL: layer-0 input order, else accumulator order)
+template <int C, bool NATURAL>
+__device__ __forceinline__ void scatter_rows(const Act<BF16>::Regs<C>& a, char* rows, int cl, int g) {
+    constexpr int KS = (C < 16 ? 16 : C) / 16;
+    char* base = rows + cl * 2 + g * (NATURAL ? 8 : 4) * RS;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const uint32_t d[4] = {a.v[s].x, a.v[s].y, a.v[s].z, a.v[s].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = NATURAL ? 16 * s + e : 16 * s + 8 * (e >> 2) + (e & 3);
+            const uint16_t hv = (e & 1) ? (uint16_t)(d[e >> 1] >> 16) : (uint16_t)(d[e >> 1] & 0xffffu);
+            *(uint16_t*)(base + ch * RS) = hv;
+        }
+    }
+}
+
+// gradient of the head wrt the raw 1x1 outputs of one cell (valid in lanes 0-31)
+template <int KUP>
+__device__ __forceinline__ void head_bwd(const f32x16_t& acc, const TileCtx& t, float (&gr)[3]) {
+    if constexpr (KUP == 1) {
+        const float sg = act_sigmoid(acc[0]);                                   // bts.py:93-96
+        const float go = (t.ok && t.g == 0) ? t.gout[t.cell] : 0.f;
+        gr[0] = go * sg * (1.f - sg);
+        gr[1] = 0.f;
+        gr[2] = 0.f;
+    } else {
+        const float r0 = __shfl(acc[0], t.cl, 64), r1 = __shfl(acc[1], t.cl, 64), r2 = __shfl(acc[2], t.cl, 64);
+        const Plane p = plane_from_raw(r0, r1, r2, t.max_depth);
+        float g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f;
+        if (t.ok) {
+            const long j = t.cell % t.w_cells, bi = t.cell / t.w_cells;
+            const float* gp = t.gout + ((size_t)bi * KUP) * ((size_t)t.w_cells * KUP) + (size_t)j * KUP;
+            constexpr int RH = KUP / 2;                                         // patch rows per half-wave
+#pragma unroll
+            for (int rr = 0; rr < RH; ++rr) {
+                const int r = t.g * RH + rr;
+                const float v = lpg_offset(r, KUP);
+                const float* q = gp + (size_t)r * t.w_cells * KUP;
+                float gv[KUP];
+                if constexpr (KUP >= 4) {
+#pragma unroll
+                    for (int c = 0; c < KUP; c += 4) {
+                        const f32x4_t tv = *(const f32x4_t*)(q + c);
+                        gv[c] = tv.x; gv[c + 1] = tv.y; gv[c + 2] = tv.z; gv[c + 3] = tv.w;
+                    }
+                } else {
+                    const float2 tv = *(const float2*)q;
+                    gv[0] = tv.x; gv[1] = tv.y;
+                }
+#pragma unroll
+                for (int c = 0; c < KUP; ++c) {
+                    const float u = lpg_offset(c, KUP);
+                    const float den = __fadd_rn(__fadd_rn(__fmul_rn(p.n1, u), __fmul_rn(p.n2, v)), p.n3);
+                    const float gi = gv[c] / (den * t.max_depth);
+                    const float gq = -gi * (p.n4 / den);
+                    g4 += gi; g1 += gq * u; g2 += gq * v; g3 += gq;
+                }
+            }
+        }
+        g1 += __shfl_xor(g1, 32, 64); g2 += __shfl_xor(g2, 32, 64); g3 += __shfl_xor(g3, 32, 64); g4 += __shfl_xor(g4, 32, 64);
+        const float dot = g1 * p.n1 + g2 * p.n2 + g3 * p.n3;
+        const float gm1 = (g1 - p.n1 * dot) * p.inv_norm;
+        const float gm2 = (g2 - p.n2 * dot) * p.inv_norm;
+        const float gm3 = (g3 - p.n3 * dot) * p.inv_norm;
+        const float gtheta = gm1 * p.ct * p.cp + gm2 * p.ct * p.sp - gm3 * p.st;
+        const float gphi = -gm1 * p.st * p.sp + gm2 * p.st * p.cp;
+        const float PI = 3.14159274101257324f;
+        gr[0] = gtheta * (PI / 3.0f) * p.s0 * (1.f - p.s0);
+        gr[1] = gphi * (PI * 2.0f) * p.s1 * (1.f - p.s1);
+        gr[2] = g4 * t.max_depth * p.s2 * (1.f - p.s2);
+    }
+}
+
+// Layer with C input channels (and everything after it).  dw[T0 ...] are this wave's weight-gradient accumulators.
+template <int C, int NOUT, int KUP, bool FIRST, int T0, int NTOT>
+struct BwdLayer {
+    static constexpr int COUT = C > 8 ? C / 2 : NOUT;
+    static constexpr int TMO = (COUT + 31) / 32, TNI = (C + 31) / 32;
+    static constexpr int KSO = (COUT < 16 ? 16 : COUT) / 16;
+    using RegsIn = Act<BF16>::Regs<C>;
+    using RegsOut = Act<BF16>::Regs<COUT>;
+
+    __device__ static __forceinline__ void run(const RegsIn& a_in, const char* wf, const char* wt, char* scr, const TileCtx& t,
+                                               f32x16_t (&dw)[NTOT], f32x16_t (&dA)[TNI]) {
+        RegsOut dz;
+        if constexpr (C > 8) {
+            RegsOut a_out;
+            dense_elu<BF16, C, COUT>(a_in, wf, t.lane, a_out);
+            f32x16_t dAo[TMO];
+            BwdLayer<COUT, NOUT, KUP, false, T0 + TMO * TNI, NTOT>::run(
+                a_out, wf + layer_bytes<BF16, C, COUT>(), wt + layer_bytes<BF16, COUT, C>(), scr + 32 * (TMO + TNI) * RS, t, dw, dAo);
+#pragma unroll
+            for (int s = 0; s < KSO; ++s) {                     // dz = dA_out * elu'(z), elu' from the (bf16) output
+                const int tm = s >> 1, q = 8 * (s & 1);
+                const uint32_t aw[4] = {a_out.v[s].x, a_out.v[s].y, a_out.v[s].z, a_out.v[s].w};
+                uint32_t o[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    o[d] = pack_bf16x2(dAo[tm][q + 2 * d] * elu_grad_from_out(bf16_lo(aw[d])),
+                                       dAo[tm][q + 2 * d + 1] * elu_grad_from_out(bf16_hi(aw[d])));
+                dz.v[s] = u32x4_t{o[0], o[1], o[2], o[3]};
+            }
+        } else {
+            f32x16_t acc;
+            dense_tile<C>(a_in, wf, t.lane, 0, acc);
+            float gr[3];
+            head_bwd<KUP>(acc, t, gr);
+            u32x4_t z = {0, 0, 0, 0};
+            if (t.g == 0) { z.x = pack_bf16x2(gr[0], gr[1]); z.y = pack_bf16x2(gr[2], 0.f); }
+            dz.v[0] = z;
+        }
+        // weight gradient: dW[co][ci] += sum_cells dz[co][cell] * a_in[ci][cell]
+        char* zr = scr;
+        char* ar = scr + 32 * TMO * RS;
+        scatter_rows<COUT, false>(dz, zr, t.cl, t.g);
+        scatter_rows<C, FIRST>(a_in, ar, t.cl, t.g);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4_t bf[TNI];
+#pragma unroll
+            for (int tn = 0; tn < TNI; ++tn) bf[tn] = *(const u32x4_t*)(ar + (32 * tn + t.cl) * RS + (16 * s + 8 * t.g) * 2);
+#pragma unroll
+            for (int tm = 0; tm < TMO; ++tm) {
+                const u32x4_t af = *(const u32x4_t*)(zr + (32 * tm + t.cl) * RS + (16 * s + 8 * t.g) * 2);
+#pragma unroll
+                for (int tn = 0; tn < TNI; ++tn)
+                    dw[T0 + tm * TNI + tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bf[tn]), dw[T0 + tm * TNI + tn], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // input gradient: dA_in = W^T dz
+#pragma unroll
+        for (int tn = 0; tn < TNI; ++tn) dense_tile<COUT>(dz, wt, t.lane, tn, dA[tn]);
+    }
+
+    // cross-wave reduction + atomics of this layer's tiles (and the deeper layers')
+    __device__ static __forceinline__ void reduce(f32x16_t (&dw)[NTOT], float* red, const ChainBwdK& a, int layer, int tid) {
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int tm = 0; tm < TMO; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TNI; ++tn) {
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = dw[T0 + tm * TNI + tn][r];
+                __syncthreads();
+                float* dst = a.dw[layer];
+                const int ld = a.dw_ld[layer];
+                for (int idx = tid; idx < 1024; idx += 256) {
+                    const int r = idx >> 6, l = idx & 63;
+                    const int co = 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ci = 32 * tn + (l & 31);
+                    if (co < COUT && ci < C) {
+                        const float v = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+                        atomicAdd(dst + (size_t)co * ld + ci, v);
+                    }
+                }
+            }
+        if constexpr (C > 8) BwdLayer<COUT, NOUT, KUP, false, T0 + TMO * TNI, NTOT>::reduce(dw, red, a, layer + 1, tid);
+    }
+};
+
+template <int C0, int KUP>
+__global__ __launch_bounds__(256) void lpg_chain_bwd_kernel(const ChainBwdK a) {
+    constexpr int NOUT = KUP == 1 ? 1 : 3;
+    constexpr int NTOT = bwd_dw_tiles<C0, NOUT>();
+    constexpr int SROWS = bwd_scr_rows<C0, NOUT>();
+    constexpr int TN0 = (C0 + 31) / 32;
+    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* wf = wlds;
+    char* wt = wlds + a.wf_bytes;
+    char* scr0 = wt + a.wt_bytes;
+    for (int i = tid * 16; i < a.wf_bytes; i += 256 * 16) *(u32x4_t*)(wf + i) = *(const u32x4_t*)(a.wf + i);
+    for (int i = tid * 16; i < a.wt_bytes; i += 256 * 16) *(u32x4_t*)(wt + i) = *(const u32x4_t*)(a.wt + i);
+    constexpr int SCR_BYTES = 4 * SROWS * RS > 16384 ? 4 * SROWS * RS : 16384;
+    for (int i = tid * 16; i < SCR_BYTES; i += 256 * 16) *(u32x4_t*)(scr0 + i) = u32x4_t{0, 0, 0, 0};   // pad rows stay zero
+    __syncthreads();
+    char* scr = scr0 + wave * SROWS * RS;
+    const int g = lane >> 5, cl = lane & 31;
+    const long ntiles = (a.cells + 31) / 32;
+    f32x16_t dw[NTOT];
+#pragma unroll
+    for (int i = 0; i < NTOT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw[i][r] = 0.f;
+    const long tstep = (long)gridDim.x * 4;
+    long tile = (long)blockIdx.x * 4 + wave;
+    Act<BF16>::Regs<C0> in, in_next;
+    auto load_tile = [&](long tl, Act<BF16>::Regs<C0>& dst) {
+        const long c = tl * 32 + cl;
+        load_input_bf16<C0>(a.x, (size_t)c, a.x_stride, tl < ntiles && c < a.cells, g, dst);
+    };
+    if (tile < ntiles) load_tile(tile, in_next);
+    for (; tile < ntiles; tile += tstep) {
+        TileCtx t;
+        t.gout = a.gout; t.cell = tile * 32 + cl; t.ok = t.cell < a.cells; t.w_cells = a.w_cells;
+        t.lane = lane; t.cl = cl; t.g = g; t.max_depth = a.max_depth;
+        in = in_next;
+        load_tile(tile + tstep, in_next);
+        f32x16_t dA[TN0];
+        BwdLayer<C0, NOUT, KUP, true, 0, NTOT>::run(in, wf, wt, scr, t, dw, dA);
+        if (t.ok) {                                        // dx: 4 consecutive channels per accumulator quad
+            char* px = (char*)a.dx + ((size_t)t.cell * a.dx_stride) * 2;
+#pragma unroll
+            for (int tn = 0; tn < TN0; ++tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = 32 * tn + 8 * q + 4 * g;
+                    if (ch < C0) {
+                        float v0 = dA[tn][4 * q], v1 = dA[tn][4 * q + 1], v2 = dA[tn][4 * q + 2], v3 = dA[tn][4 * q + 3];
+                        uint2* dst = (uint2*)(px + ch * 2);
+                        if (a.dx_accumulate) {
+                            const uint2 o = *dst;
+                            v0 += bf16_lo(o.x); v1 += bf16_hi(o.x); v2 += bf16_lo(o.y); v3 += bf16_hi(o.y);
+                        }
+                        *dst = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    BwdLayer<C0, NOUT, KUP, true, 0, NTOT>::reduce(dw, (float*)scr0, a, 0, tid);
+}
+
+template <int C0, int KUP>
+int launch_chain_bwd(const ChainBwdK& k, hipStream_t st) {
+    constexpr int NOUT = KUP == 1 ? 1 : 3;
+    constexpr int SROWS = bwd_scr_rows<C0, NOUT>();
+    constexpr int SCR_BYTES = 4 * SROWS * RS > 16384 ? 4 * SROWS * RS : 16384;
+    auto kern = lpg_chain_bwd_kernel<C0, KUP>;
+    const int lds = k.wf_bytes + k.wt_bytes + SCR_BYTES;
+    if (lds > 160 * 1024) return BTS_ERR_UNSUPPORTED;
+    static int lds_set = 0;      // per instantiation; not a stream operation, so done once outside any graph capture window
+    if (lds > 48 * 1024 && lds > lds_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return BTS_ERR_LAUNCH;
+        lds_set = lds;
+    }
+    const long ntiles = (k.cells + 31) / 32;
+    long blocks = (ntiles + 3) / 4;
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    if (blocks > 256l * per_cu) blocks = 256l * per_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), (size_t)lds, st, k);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
 }  // namespace
 
 extern "C" int bts_lpg_chain_fwd(const void* x, int dtype, int x_stride, int c0, int same_first, const void* w_frags,
@@ -283,4 +589,37 @@ extern "C" int bts_lpg_chain_fwd(const void* x, int dtype, int x_stride, int c0,
     k.h = in_h; k.w_cells = in_w; k.max_depth = max_depth;
     return dtype == BTS_F32 ? dispatch_chain<F32>(k, c0, same_first, upratio, (hipStream_t)stream)
                             : dispatch_chain<BF16>(k, c0, same_first, upratio, (hipStream_t)stream);
+}
+
+extern "C" int bts_lpg_chain_bwd(const void* x, int dtype, int x_stride, int c0, const void* w_frags, int w_bytes,
+                                 const void* wt_frags, int wt_bytes, const float* grad_out, void* grad_x, int grad_x_stride,
+                                 int accumulate, float* const* grad_w, const int* grad_w_ld, int n_layers, long cells,
+                                 int in_h, int in_w, int upratio, float max_depth, bts_stream_t stream) {
+    BTS_CHECK_ARG(x && w_frags && wt_frags && grad_out && grad_x && grad_w && grad_w_ld && cells > 0 && in_h > 0 && in_w > 0);
+    BTS_CHECK_ARG(w_bytes > 0 && w_bytes % 1024 == 0 && wt_bytes > 0 && wt_bytes % 1024 == 0);
+    BTS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_frags & 15) == 0 && ((uintptr_t)wt_frags & 15) == 0);
+    BTS_CHECK_ARG(((uintptr_t)grad_x & 7) == 0 && ((uintptr_t)grad_out & 15) == 0 && n_layers >= 2 && n_layers <= 6);
+    BTS_CHECK_ARG(cells % ((long)in_h * in_w) == 0);
+    if (dtype != BTS_BF16) return BTS_ERR_UNSUPPORTED;      // f32 (parity mode) trains layer by layer
+    BTS_CHECK_ARG(x_stride % 8 == 0 && x_stride >= c0 && grad_x_stride % 4 == 0 && grad_x_stride >= c0);
+    int expect = 1;
+    for (int c = c0; c > 8; c >>= 1) ++expect;
+    BTS_CHECK_ARG(n_layers == expect);
+    ChainBwdK k{};
+    k.x = x; k.x_stride = x_stride;
+    k.wf = (const char*)w_frags; k.wf_bytes = w_bytes;
+    k.wt = (const char*)wt_frags; k.wt_bytes = wt_bytes;
+    k.gout = grad_out; k.dx = grad_x; k.dx_stride = grad_x_stride; k.dx_accumulate = accumulate;
+    for (int l = 0; l < n_layers; ++l) {
+        BTS_CHECK_ARG(grad_w[l] && grad_w_ld[l] > 0);
+        k.dw[l] = grad_w[l]; k.dw_ld[l] = grad_w_ld[l];
+    }
+    k.cells = cells; k.h = in_h; k.w_cells = in_w; k.max_depth = max_depth;
+    hipStream_t st = (hipStream_t)stream;
+#define CASE(C, K) if (c0 == C && upratio == K) return launch_chain_bwd<C, K>(k, st)
+    CASE(64, 2); CASE(32, 1);               // bts_size 512: reduc2x2, reduc1x1 (bts.py:186, 190)
+    CASE(64, 4); CASE(32, 2); CASE(16, 1);  // bts_size 256
+    CASE(32, 4); CASE(16, 2);               // bts_size 128
+#undef CASE
+    return BTS_ERR_UNSUPPORTED;
 }

@@ -12,6 +12,7 @@ statistics, LPG heads and the five outputs are f32.  torch.cat never happens: ev
 its concatenated input as a list of segments.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -24,6 +25,8 @@ from .ops import pad_to, vec_of
 
 KITTI_FOCAL_REF = 715.0873  # bts.py:264
 BN_MOMENTUM = 0.01          # bts.py:154 etc.
+# fused recompute backward of the narrow LPG chains (A/B switch for measurements: BTS_CHAIN_BWD=0 trains them layer-wise)
+FUSED_CHAIN_BWD = os.environ.get("BTS_CHAIN_BWD", "1") != "0"
 
 
 def reduction_specs(c_in, c_out, is_final):
@@ -329,26 +332,51 @@ class DecoderRun:
             self.tape.append(bwd)
         return y
 
+    def _chain_pack(self, name, ws, with_t):
+        """Fragment buffers of a chain, repacked from the live weights on every pass (two gathers through cached
+        indices): nothing keyed on tensor versions, so in-place / graph-replayed optimizer updates are always seen."""
+        cache = self.plan.chain_cache
+        key = (name, self.dtype)
+        pk = cache.get(key)
+        if pk is None or pk.idx_fwd.device != ws[0].device:
+            pk = chain_mod.ChainPacker([(w.shape[0], w.shape[1]) for w in ws], self.dtype, ws[0].device)
+            cache[key] = pk
+        return pk.pack(ws, with_t)
+
     def chain_fused(self, name, x, k):
-        """Inference-only: whole reduction_1x1 chain (+ plane head + LPG for k > 1) in one kernel
-        (csrc/lpg_chain.hip).  Returns None when the chain shape has no instantiation."""
+        """Whole reduction_1x1 chain (+ plane head + LPG for k > 1) in one kernel (csrc/lpg_chain.hip).  Without
+        recording: any instantiated shape.  With recording: only shapes that also have the fused recompute backward
+        (narrow bf16 chains); the forward then stores nothing but its input.  Returns None otherwise."""
         keys = self.plan.reduc[name]
         ws = [self.P[key + ".weight"] for key in keys]
         c0, same = ws[0].shape[1], ws[0].shape[0] == ws[0].shape[1]
         if not chain_mod.supported(c0, same, k) or x.t.shape[3] != c0:
             return None
-        ck = (name, self.dtype, tuple((w.data_ptr(), w._version) for w in ws))
-        cache = self.plan.chain_cache
-        if cache.get(name, (None,))[0] != ck:
-            cache[name] = (ck, chain_mod.pack_chain(ws, self.dtype))
-        return Act(chain_mod.chain_fwd(x.t, cache[name][1], c0, same, k, self.max_depth))
+        train = self.record
+        if train and not (FUSED_CHAIN_BWD and chain_mod.bwd_supported(c0, same, k, self.dtype)):
+            return None
+        frags, frags_t = self._chain_pack(name, ws, train)
+        d = Act(chain_mod.chain_fwd(x.t, frags, c0, same, k, self.max_depth))
+        if train:
+            def bwd():
+                if d.g is None:
+                    return
+                acc = x.g is not None
+                if not acc:
+                    x.g = torch.empty(x.t.shape, dtype=self.dtype, device=x.t.device)
+                gws = []
+                for key in keys:
+                    off, shape = self.packs.dwp_off[key]
+                    gws.append(self.dwp_arena[off:off + shape[0] * shape[1] * shape[2]].view(shape[0], shape[1] * shape[2]))
+                chain_mod.chain_bwd(x.t, frags, frags_t, c0, k, self.max_depth, d.g, x.g, acc, gws)
+            self.tape.append(bwd)
+        return d
 
     def lpg_branch(self, name, x, k):
-        """reduction chain + LPG head: fused kernel when no gradient is recorded, layer-wise otherwise."""
-        if not self.record:
-            d = self.chain_fused(name, x, k)
-            if d is not None:
-                return d
+        """reduction chain + LPG head: one fused kernel where an instantiation exists, layer-wise otherwise."""
+        d = self.chain_fused(name, x, k)
+        if d is not None:
+            return d
         y = self.chain(name, x)
         return y if k == 1 else self.head(y, k)
 

@@ -93,4 +93,6 @@ class FusedAdamW(torch.optim.Optimizer):
                  C.c_void_p(t["m1"].data_ptr()), C.c_void_p(t["m2"].data_ptr()), C.c_void_p(t["sizes"].data_ptr()),
                  t["n"], t["max_size"], 0.0, float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), 1.0, 1.0,
                  C.c_void_p(hyper.data_ptr()), stream_ptr())
+            # parameters were updated through raw pointers: tell autograd / any version-keyed cache
+            torch.autograd.graph.increment_version(plist)
         return None

@@ -98,6 +98,20 @@ int bts_lpg_chain_fwd(const void* x, int dtype, int x_stride, int c0, int same_f
                       int w_bytes, float* out, long cells, int in_h, int in_w, int upratio, float max_depth,
                       bts_stream_t stream);
 
+/* Training backward of the same fused head for the narrow halving chains (c0 <= 64, bf16): recomputes the chain
+ * from x, differentiates sigmoid / plane / normalise / LPG (or the reduc1x1 sigmoid) in registers, and produces in
+ * ONE pass the gradient of x and of every 1x1 weight of the chain -- what autograd does layer by layer through
+ * bts.py:83-122, 124-146 (parity target: PyTorch autograd of the reference module).
+ *   wt_frags   per layer, W^T packed as A fragments in accumulator K order (bts_amd/chain.py::pack_chain_t)
+ *   grad_out   f32: [B][h*k][w*k] gradient of the depth map (k = 8/4/2) or [cells] of the sigmoid map (k = 1)
+ *   grad_x     [cells][grad_x_stride] in `dtype`; accumulate != 0 adds to its contents
+ *   grad_w     n_layers pointers: f32 [Cout_l][grad_w_ld[l]], accumulated with atomics (caller zeroes)
+ * Returns BTS_ERR_UNSUPPORTED for f32 or chain shapes without an instantiation (caller runs the layer-wise path). */
+int bts_lpg_chain_bwd(const void* x, int dtype, int x_stride, int c0, const void* w_frags, int w_bytes,
+                      const void* wt_frags, int wt_bytes, const float* grad_out, void* grad_x, int grad_x_stride,
+                      int accumulate, float* const* grad_w, const int* grad_w_ld, int n_layers, long cells,
+                      int in_h, int in_w, int upratio, float max_depth, bts_stream_t stream);
+
 /* Gather up to 4 single-channel f32 maps into channels 0..n-1 of an NHWC buffer (the depth-map
  * slots of the concat inputs of conv3 / conv2 / conv1, bts.py:233, 247, 260): dst pixel (n,y,x)
  * channel s = src[s][n][y*ds[s]][x*ds[s]] where src[s] is [N][H*ds[s]][W*ds[s]]

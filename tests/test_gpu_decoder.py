@@ -208,7 +208,7 @@ def test_fused_adamw_matches_torch_adamw():
 
 @pytest.mark.parametrize("nf,feat", [(512, [96, 96, 192, 384, 2208]), (128, [8, 8, 16, 24, 40])])
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
-def test_fused_inference_chain_matches_layerwise(nf, feat, dt, tol):
+def test_fused_inference_chain_matches_layerwise(nf, feat, dt, tol, monkeypatch):
     """no-grad forward uses the fused reduction-chain + LPG kernel (csrc/lpg_chain.hip); it must agree with the
     layer-wise path (taken when gradients are recorded) and, in f32, with the oracle to 1e-4."""
     B, H, W = 2, 64, 96
@@ -218,11 +218,12 @@ def test_fused_inference_chain_matches_layerwise(nf, feat, dt, tol):
     focal = O.synth_focal(B, "kitti")
     dec, _ = build(feat, nf, "kitti", P, dtype=dt, train=False)
     fs = [f.to(DEV) for f in feats]
-    from bts_amd import profiler
+    from bts_amd import decoder as decoder_mod, profiler
     prof = profiler.enable()
     with torch.no_grad():
         fused = dec(fs, focal.to(DEV))
     names = {r[0] for r in prof.records}
+    monkeypatch.setattr(decoder_mod, "FUSED_CHAIN_BWD", False)      # recorded pass: every chain layer by layer
     layerwise = dec([f.clone().requires_grad_(True) for f in fs], focal.to(DEV))
     names2 = {r[0] for r in prof.records} - names
     profiler.disable()
@@ -235,6 +236,36 @@ def test_fused_inference_chain_matches_layerwise(nf, feat, dt, tol):
         ref, _ = O.decoder_forward(P, feats, focal, 80.0, "kitti", False)
         for a, r in zip(fused, ref):
             assert rel(a, r) < 1e-4
+
+
+@pytest.mark.parametrize("nf,feat", [(512, [96, 96, 192, 384, 2208]), (256, [16, 16, 32, 48, 80]), (128, [8, 8, 16, 24, 40])])
+def test_fused_train_chain_matches_layerwise(nf, feat, monkeypatch):
+    """bf16 training: the narrow LPG chains (reduc2x2 / reduc1x1 at bts_size 512) run as one fused forward and one
+    fused recompute-backward kernel; outputs and every gradient must agree with the layer-wise schedule to bf16 noise."""
+    from bts_amd import decoder as decoder_mod, profiler
+    B, H, W = 2, 64, 96
+    gen = torch.Generator().manual_seed(43)
+    P = O.make_decoder_params(feat, nf, gen, randomize_bn=True)
+    feats = O.make_features(feat, B, H, W, gen)
+    focal = O.synth_focal(B, "kitti")
+    gt = O.synth_depth_gt(B, H, W, "kitti", gen)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(decoder_mod, "FUSED_CHAIN_BWD", fused)
+        dec, _ = build(feat, nf, "kitti", P, dtype=torch.bfloat16)
+        prof = profiler.enable()
+        fs, outs, loss, aux = run(dec, feats, focal, gt, "kitti")
+        names = {r[0] for r in prof.records}
+        profiler.disable()
+        assert any(n.startswith("lpg_head_chain_bwd") for n in names) == fused, names
+        res[fused] = ([o.detach() for o in outs], {n: p.grad for n, p in dec.named_parameters()}, [f.grad for f in fs])
+    for a, b in zip(res[True][0], res[False][0]):
+        assert rel(a, b) < 3e-2
+    worst = {n: rel(g, res[False][1][n]) for n, g in res[True][1].items()}
+    print(sorted(worst.items(), key=lambda kv: -kv[1])[:6])
+    assert max(worst.values()) < 6e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:6]
+    for a, b in zip(res[True][2], res[False][2]):
+        assert rel(a, b) < 6e-2
 
 
 @pytest.mark.parametrize("enc", ["densenet121_bts", "resnet50_bts"])

@@ -257,3 +257,44 @@ def test_layout_roundtrip_and_pack_maps():
     ops.unpack_maps(g, gm, [1, 1, 1, 1])
     for s in range(4):
         assert torch.equal(gm[s], g[..., s])
+
+
+@pytest.mark.parametrize("c0,k", [(64, 2), (32, 1), (16, 2), (64, 4), (16, 1), (32, 4)])
+@pytest.mark.parametrize("acc", [False, True])
+def test_lpg_chain_bwd_vs_autograd(c0, k, acc):
+    """Fused recompute backward of a narrow reduction chain + head (csrc/lpg_chain.hip) against PyTorch autograd of
+    the same chain written with torch ops on the bf16-rounded inputs (f32 math; the kernel rounds the intermediate
+    activations and gradients to bf16, hence the 3e-2 max-norm bar).  Cell count is not a multiple of the 32-cell tile."""
+    import torch.nn.functional as F
+    from bts_amd import chain
+    gen = torch.Generator().manual_seed(7 * c0 + k)
+    B, h, w, md = 2, 13, 21, 80.0
+    dims = [c0]
+    while dims[-1] > 8:
+        dims.append(dims[-1] // 2)
+    dims.append(3 if k > 1 else 1)
+    ws = [(torch.randn(dims[i + 1], dims[i], 1, 1, generator=gen) * (2.0 / dims[i]) ** 0.5).bfloat16().float() for i in range(len(dims) - 1)]
+    x = torch.randn(B, h, w, c0, generator=gen).bfloat16()
+    xr = x.float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr = [wi.clone().requires_grad_(True) for wi in ws]
+    a = xr
+    for i, wi in enumerate(wr):
+        a = F.conv2d(a, wi)
+        if i < len(wr) - 1:
+            a = F.elu(a)
+    ref = O.lpg(O.normalize_plane(O.plane_from_raw(a, md)), k) / md if k > 1 else torch.sigmoid(a)
+    gy = torch.randn(ref.shape, generator=gen)
+    ref.backward(gy)
+    wd = [wi.to(DEV) for wi in ws]
+    frags, frags_t = chain.pack_chain(wd, torch.bfloat16), chain.pack_chain_t(wd, torch.bfloat16)
+    xd = x.to(DEV)
+    out = chain.chain_fwd(xd, frags, c0, False, k, md)
+    assert rel(out, ref.reshape(out.shape)) < 2e-2
+    gx0 = torch.randn(B, h, w, c0, generator=gen).bfloat16()
+    gx = gx0.to(DEV) if acc else torch.full((B, h, w, c0), float("nan"), dtype=torch.bfloat16, device=DEV)
+    gws = [torch.zeros(dims[i + 1], max(dims[i], 8), device=DEV) for i in range(len(dims) - 1)]
+    chain.chain_bwd(xd, frags, frags_t, c0, k, md, gy.reshape(out.shape).to(DEV).contiguous(), gx, acc, gws)
+    want = xr.grad.permute(0, 2, 3, 1) + (gx0.float() if acc else 0.0)
+    assert rel(gx.float(), want) < 3e-2
+    for g, wi in zip(gws, wr):
+        assert rel(g[:, :wi.shape[1]], wi.grad.reshape(wi.shape[0], wi.shape[1])) < 3e-2
