@@ -294,7 +294,13 @@ def test_lpg_chain_bwd_vs_autograd(c0, k, acc):
     gx = gx0.to(DEV) if acc else torch.full((B, h, w, c0), float("nan"), dtype=torch.bfloat16, device=DEV)
     gws = [torch.zeros(dims[i + 1], max(dims[i], 8), device=DEV) for i in range(len(dims) - 1)]
     chain.chain_bwd(xd, frags, frags_t, c0, k, md, gy.reshape(out.shape).to(DEV).contiguous(), gx, acc, gws)
+    def rel_l2(a_, b_):
+        a_, b_ = a_.detach().double().cpu(), b_.detach().double().cpu()
+        return ((a_ - b_).norm() / b_.norm()).item()
     want = xr.grad.permute(0, 2, 3, 1) + (gx0.float() if acc else 0.0)
-    assert rel(gx.float(), want) < 3e-2
+    # bf16 rounding of dz / activations at every layer: ~1 % per element, a few % on the ill-conditioned planes
+    assert rel_l2(gx.float(), want) < 2e-2 and rel(gx.float(), want) < 8e-2
     for g, wi in zip(gws, wr):
-        assert rel(g[:, :wi.shape[1]], wi.grad.reshape(wi.shape[0], wi.shape[1])) < 3e-2
+        ref_g = wi.grad.reshape(wi.shape[0], wi.shape[1])
+        assert rel_l2(g[:, :wi.shape[1]], ref_g) < 2e-2 and rel(g[:, :wi.shape[1]], ref_g) < 5e-2
+        assert g[:, wi.shape[1]:].abs().max().item() == 0.0 if g.shape[1] > wi.shape[1] else True
