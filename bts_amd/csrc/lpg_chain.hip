@@ -280,12 +280,12 @@ int dispatch_chain(const ChainK& k, int c0, int same_first, int kup, hipStream_t
 // atomics per workgroup at the end.  HBM traffic: x once, grad_out once, dx once (+ read when accumulating).
 constexpr int RS = 80;   // scratch row stride in bytes: 32 cells * 2 B + 16 B skew
 
+// scratch rows of one wave: the widest layer's (32-row padded) dz + a_in operands.  Every layer reuses the same rows:
+// stale rows beyond a narrower layer's channels only feed dW rows / columns that are never written out.
 template <int C, int NOUT>
 constexpr int bwd_scr_rows() {
     constexpr int cout = C > 8 ? C / 2 : NOUT;
-    int rows = 32 * ((cout + 31) / 32) + 32 * ((C + 31) / 32);
-    if constexpr (C > 8) rows += bwd_scr_rows<C / 2, NOUT>();
-    return rows;
+    return 32 * ((cout + 31) / 32) + 32 * ((C + 31) / 32);
 }
 template <int C, int NOUT>
 constexpr int bwd_dw_tiles() {
@@ -415,7 +415,7 @@ struct BwdLayer {
             dense_elu<BF16, C, COUT>(a_in, wf, t.lane, a_out);
             f32x16_t dAo[TMO];
             BwdLayer<COUT, NOUT, KUP, false, T0 + TMO * TNI, NTOT>::run(
-                a_out, wf + layer_bytes<BF16, C, COUT>(), wt + layer_bytes<BF16, COUT, C>(), scr + 32 * (TMO + TNI) * RS, t, dw, dAo);
+                a_out, wf + layer_bytes<BF16, C, COUT>(), wt + layer_bytes<BF16, COUT, C>(), scr, t, dw, dAo);
 #pragma unroll
             for (int s = 0; s < KSO; ++s) {                     // dz = dA_out * elu'(z), elu' from the (bf16) output
                 const int tm = s >> 1, q = 8 * (s & 1);
@@ -489,7 +489,7 @@ struct BwdLayer {
 };
 
 template <int C0, int KUP>
-__global__ __launch_bounds__(256) void lpg_chain_bwd_kernel(const ChainBwdK a) {
+__global__ __launch_bounds__(256, 2) void lpg_chain_bwd_kernel(const ChainBwdK a) {
     constexpr int NOUT = KUP == 1 ? 1 : 3;
     constexpr int NTOT = bwd_dw_tiles<C0, NOUT>();
     constexpr int SROWS = bwd_scr_rows<C0, NOUT>();
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void lpg_chain_bwd_kernel(const ChainBwdK a) {
     for (int i = tid * 16; i < a.wf_bytes; i += 256 * 16) *(u32x4_t*)(wf + i) = *(const u32x4_t*)(a.wf + i);
     for (int i = tid * 16; i < a.wt_bytes; i += 256 * 16) *(u32x4_t*)(wt + i) = *(const u32x4_t*)(a.wt + i);
     constexpr int SCR_BYTES = 4 * SROWS * RS > 16384 ? 4 * SROWS * RS : 16384;
-    for (int i = tid * 16; i < SCR_BYTES; i += 256 * 16) *(u32x4_t*)(scr0 + i) = u32x4_t{0, 0, 0, 0};   // pad rows stay zero
+    for (int i = tid * 16; i < SCR_BYTES; i += 256 * 16) *(u32x4_t*)(scr0 + i) = u32x4_t{0, 0, 0, 0};
     __syncthreads();
     char* scr = scr0 + wave * SROWS * RS;
     const int g = lane >> 5, cl = lane & 31;
@@ -567,7 +567,8 @@ int launch_chain_bwd(const ChainBwdK& k, hipStream_t st) {
     }
     const long ntiles = (k.cells + 31) / 32;
     long blocks = (ntiles + 3) / 4;
-    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    int per_cu = C0 >= 64 ? 2 : 4;                   // resident workgroups per CU allowed by registers ...
+    if (per_cu > 160 * 1024 / lds) per_cu = 160 * 1024 / lds;      // ... and by LDS
     if (blocks > 256l * per_cu) blocks = 256l * per_cu;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), (size_t)lds, st, k);
     BTS_LAUNCH_CHECK();
