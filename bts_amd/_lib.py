@@ -46,13 +46,13 @@ class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("cmap", C.c_void_p),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("KK", C.c_int32), ("mode", C.c_int32),
                 ("R", C.c_int32), ("K", C.c_int32), ("T", C.c_int32),
-                ("tapmask", C.c_uint16 * MAX_TAP), ("pad_", C.c_int32)]
+                ("tapmask", C.c_uint16 * MAX_TAP), ("first_block", C.c_int32)]
 
 
 class UnpackJob(C.Structure):
     _fields_ = [("dwp_off", C.c_int64), ("gw_off", C.c_int64), ("kinv", C.c_void_p),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("KK", C.c_int32), ("K", C.c_int32), ("T", C.c_int32),
-                ("tapmask", C.c_uint16 * MAX_TAP), ("pad_", C.c_int32)]
+                ("tapmask", C.c_uint16 * MAX_TAP), ("first_block", C.c_int32)]
 
 
 _i, _l, _f, _p = C.c_int, C.c_long, C.c_float, C.c_void_p

@@ -1019,44 +1019,104 @@ __global__ void unpack_wgrad_kernel(const PackK a) {
     }
 }
 
-// multi-tensor variants: one launch packs (unpacks) every layer of the decoder; the job table lives on the device
+// multi-tensor variants: one launch packs (unpacks) every layer of the decoder; the job table lives on the device.
+// Work is cut into equal units (32 x 32 (co, ci) tiles for packing, 256 (co, ci) pairs for unpacking) and every job
+// owns the block range [first_block, next job's first_block), so a 10 M-element upconv and a 24-element head get
+// blocks in proportion to their size.  All global traffic is coalesced: the f32 weights are read along ci (the
+// contiguous [ci][tap] run of one output channel) into an LDS tile, and written along k for the forward operand
+// (mode 0) or along co for the transposed data-gradient operand (mode 1).
+constexpr int PACK_TILE = 32;
+constexpr int PACK_ROW = PACK_TILE * 9 + 1;      // f32 per co row of the LDS tile (+1: conflict-free when co is the fast index)
+
+template <typename J>
+__device__ __forceinline__ int find_job(const J* __restrict__ jobs, int n_jobs, int block) {
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= block) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 template <typename T>
-__global__ void pack_weight_batch_kernel(const bts_pack_job_t* __restrict__ jobs) {
-    const bts_pack_job_t j = jobs[blockIdx.y];
-    const long total = (long)j.R * j.T * j.K;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(idx % j.K);
-        const int t = (int)((idx / j.K) % j.T);
-        const int r = (int)(idx / ((long)j.K * j.T));
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const bts_pack_job_t* __restrict__ jobs, int n_jobs) {
+    __shared__ float tile[PACK_TILE * PACK_ROW];
+    __shared__ int ci_s[PACK_TILE];
+    __shared__ uint32_t mask_s[BTS_MAX_TAP];
+    const int tid = threadIdx.x;
+    const bts_pack_job_t& j = jobs[find_job(jobs, n_jobs, (int)blockIdx.x)];
+    const int KK = j.KK, Tn = j.T, mode = j.mode, R = j.R, K = j.K, Cout = j.Cout, Cin = j.Cin;
+    const int NE = mode == 0 ? K : R;                        // entries along the input-channel map
+    const int te = (NE + PACK_TILE - 1) / PACK_TILE;
+    const int lb = (int)blockIdx.x - j.first_block;
+    const int co0 = (lb / te) * PACK_TILE, e0 = (lb % te) * PACK_TILE;
+    if (tid < PACK_TILE) ci_s[tid] = e0 + tid < NE ? j.cmap[e0 + tid] : -1;
+    if (tid >= 64 && tid < 64 + BTS_MAX_TAP) mask_s[tid - 64] = tid - 64 < Tn ? j.tapmask[tid - 64] : 0u;
+    __syncthreads();
+    const int run = PACK_TILE * KK;
+    for (int i = tid; i < PACK_TILE * run; i += 256) {
+        const int co = i / run, rem = i - co * run;
+        const int e = rem / KK, sidx = rem - e * KK;
+        const int ci = ci_s[e];
         float v = 0.f;
-        int co, ci;
-        if (j.mode == 0) { co = r; ci = j.cmap[k]; }
-        else { co = k; ci = j.cmap[r]; }
-        if (ci >= 0 && co < j.Cout) {
-            const float* p = j.w + ((size_t)co * j.Cin + ci) * j.KK;
-            const uint32_t mask = j.tapmask[t];
-            for (int s = 0; s < j.KK; ++s) if (mask & (1u << s)) v += p[s];
+        if (ci >= 0 && co0 + co < Cout) v = j.w[((size_t)(co0 + co) * Cin + ci) * KK + sidx];
+        tile[co * PACK_ROW + rem] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PACK_TILE * PACK_TILE / 256; ++q) {
+        const int p = tid + 256 * q;
+        const int fast = p & (PACK_TILE - 1), slow = p / PACK_TILE;
+        const int co = mode == 0 ? slow : fast, e = mode == 0 ? fast : slow;
+        const int r = mode == 0 ? co0 + co : e0 + e, k = mode == 0 ? e0 + e : co0 + co;
+        if (r >= R || k >= K) continue;
+        const float* src = tile + co * PACK_ROW + e * KK;
+        float wv[9];
+#pragma unroll
+        for (int sidx = 0; sidx < 9; ++sidx) wv[sidx] = sidx < KK ? src[sidx] : 0.f;
+        for (int t = 0; t < Tn; ++t) {
+            const uint32_t mask = mask_s[t];
+            float v = 0.f;
+#pragma unroll
+            for (int sidx = 0; sidx < 9; ++sidx) if (mask & (1u << sidx)) v += wv[sidx];
+            T::st(j.out, ((size_t)r * Tn + t) * K + k, v);
         }
-        T::st(j.out, idx, v);
     }
 }
 
-__global__ void unpack_wgrad_batch_kernel(const bts_unpack_job_t* __restrict__ jobs, const float* __restrict__ dwp_base,
-                                          float* __restrict__ gw_base) {
-    const bts_unpack_job_t j = jobs[blockIdx.y];
+__global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const bts_unpack_job_t* __restrict__ jobs, int n_jobs,
+                                                                 const float* __restrict__ dwp_base, float* __restrict__ gw_base) {
+    __shared__ float stage[256 * 9];
+    __shared__ uint32_t mask_s[BTS_MAX_TAP];
+    const int tid = threadIdx.x;
+    const bts_unpack_job_t& j = jobs[find_job(jobs, n_jobs, (int)blockIdx.x)];
+    const int KK = j.KK, Tn = j.T, K = j.K, Cin = j.Cin;
     const float* dwp = dwp_base + j.dwp_off;
     float* gw = gw_base + j.gw_off;
-    const long total = (long)j.Cout * j.Cin * j.KK;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int s = (int)(idx % j.KK);
-        const int ci = (int)((idx / j.KK) % j.Cin);
-        const int co = (int)(idx / ((long)j.KK * j.Cin));
+    const long pairs = (long)j.Cout * Cin;
+    const long p0 = (long)((int)blockIdx.x - j.first_block) * 256;
+    if (tid < BTS_MAX_TAP) mask_s[tid] = tid < Tn ? j.tapmask[tid] : 0u;
+    __syncthreads();
+    const long p = p0 + tid;
+    if (p < pairs) {
+        const int co = (int)(p / Cin), ci = (int)(p - (long)co * Cin);
         const int k = j.kinv[ci];
-        float v = 0.f;
-        for (int t = 0; t < j.T; ++t)
-            if (j.tapmask[t] & (1u << s)) v += dwp[((size_t)co * j.T + t) * j.K + k];
-        gw[idx] = v;
+        float acc[9];
+#pragma unroll
+        for (int sidx = 0; sidx < 9; ++sidx) acc[sidx] = 0.f;
+        for (int t = 0; t < Tn; ++t) {
+            const float v = dwp[((size_t)co * Tn + t) * K + k];
+            const uint32_t mask = mask_s[t];
+#pragma unroll
+            for (int sidx = 0; sidx < 9; ++sidx) if (mask & (1u << sidx)) acc[sidx] += v;
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < 9; ++sidx) if (sidx < KK) stage[tid * KK + sidx] = acc[sidx];
     }
+    __syncthreads();
+    const long left = pairs - p0;
+    const int n_out = (int)(left < 256 ? left : 256) * KK;
+    for (int i = tid; i < n_out; i += 256) gw[p0 * KK + i] = stage[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1292,23 +1352,20 @@ extern "C" int bts_unpack_wgrad(const float* dwp, int Cout, int Cin, int KK, con
     return BTS_OK;
 }
 
-extern "C" int bts_pack_weight_batch(const bts_pack_job_t* jobs, int n_jobs, long max_elems, int dtype, bts_stream_t stream) {
-    BTS_CHECK_ARG(jobs && n_jobs > 0 && max_elems > 0 && (dtype == BTS_F32 || dtype == BTS_BF16));
-    long bx = (max_elems + 256 * 4 - 1) / (256 * 4);
-    if (bx > 256) bx = 256;
-    dim3 grid((unsigned)bx, (unsigned)n_jobs);
-    if (dtype == BTS_F32) hipLaunchKernelGGL(pack_weight_batch_kernel<F32>, grid, dim3(256), 0, (hipStream_t)stream, jobs);
-    else hipLaunchKernelGGL(pack_weight_batch_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, jobs);
+extern "C" int bts_pack_weight_batch(const bts_pack_job_t* jobs, int n_jobs, long total_blocks, int dtype, bts_stream_t stream) {
+    BTS_CHECK_ARG(jobs && n_jobs > 0 && total_blocks > 0 && total_blocks < (1l << 31) && (dtype == BTS_F32 || dtype == BTS_BF16));
+    dim3 grid((unsigned)total_blocks);
+    if (dtype == BTS_F32) hipLaunchKernelGGL(pack_weight_batch_kernel<F32>, grid, dim3(256), 0, (hipStream_t)stream, jobs, n_jobs);
+    else hipLaunchKernelGGL(pack_weight_batch_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, jobs, n_jobs);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }
 
-extern "C" int bts_unpack_wgrad_batch(const bts_unpack_job_t* jobs, int n_jobs, long max_elems, const float* dwp_base,
+extern "C" int bts_unpack_wgrad_batch(const bts_unpack_job_t* jobs, int n_jobs, long total_blocks, const float* dwp_base,
                                       float* gw_base, bts_stream_t stream) {
-    BTS_CHECK_ARG(jobs && n_jobs > 0 && max_elems > 0 && dwp_base && gw_base);
-    long bx = (max_elems + 256 * 4 - 1) / (256 * 4);
-    if (bx > 256) bx = 256;
-    hipLaunchKernelGGL(unpack_wgrad_batch_kernel, dim3((unsigned)bx, (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream, jobs, dwp_base, gw_base);
+    BTS_CHECK_ARG(jobs && n_jobs > 0 && total_blocks > 0 && total_blocks < (1l << 31) && dwp_base && gw_base);
+    hipLaunchKernelGGL(unpack_wgrad_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs,
+                       dwp_base, gw_base);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }

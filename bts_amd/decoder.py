@@ -96,6 +96,10 @@ class DecoderPlan:
         self.pack_cache = {}
 
 
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
 class PackSet:
     """Packed operands of EVERY conv of the decoder for one (dtype, device): persistent output buffers plus
     device-resident job tables, so a step issues one `bts_pack_weight_batch` for the forward operands, one for the
@@ -109,7 +113,6 @@ class PackSet:
         self.fwd, self.dgrad = {}, {}
         self.dwp_off, self.gw_off = {}, {}
         fjobs, djobs, ujobs = [], [], []
-        self.fmax = self.dmax = self.umax = 1
         dwp_total = gw_total = 0
         for n in names:
             L = plan.layers[n]
@@ -119,12 +122,10 @@ class PackSet:
             out = torch.empty((L.cout, ttot, tb["ktot"]), dtype=dtype, device=dev)
             self.fwd[n] = out
             fjobs.append(self._pjob(w, out, tb["cmap"], L, 0, L.cout, tb["ktot"], ttot))
-            self.fmax = max(self.fmax, out.numel())
             for i, rows in enumerate(tb["seg_rows"]):
                 o = torch.empty((rows.numel(), ttot, tb["cout_pad"]), dtype=dtype, device=dev)
                 self.dgrad[(n, i)] = o
                 djobs.append(self._pjob(w, o, rows, L, 1, rows.numel(), tb["cout_pad"], ttot))
-                self.dmax = max(self.dmax, o.numel())
             self.dwp_off[n] = (dwp_total, (L.cout, ttot, tb["ktot"]))
             self.gw_off[n] = (gw_total, tuple(w.shape))
             uj = _lib.UnpackJob()
@@ -133,13 +134,24 @@ class PackSet:
             for t, m in enumerate(L.masks):
                 uj.tapmask[t] = m
             ujobs.append(uj)
-            self.umax = max(self.umax, w.numel())
             dwp_total += L.cout * ttot * tb["ktot"]
             gw_total += w.numel()
         self.dwp_total, self.gw_total = dwp_total, gw_total
+        # block ranges (include/bts_amd.h: 32x32 (co, ci) tiles per pack job, 256 (co, ci) pairs per unpack block)
+        self.fblocks = self._assign(fjobs, lambda j: _cdiv(j.R if j.mode == 0 else j.K, 32) * _cdiv(j.K if j.mode == 0 else j.R, 32))
+        self.dblocks = self._assign(djobs, lambda j: _cdiv(j.R if j.mode == 0 else j.K, 32) * _cdiv(j.K if j.mode == 0 else j.R, 32))
+        self.ublocks = self._assign(ujobs, lambda j: _cdiv(j.Cout * j.Cin, 256))
         self.fjobs, self.nf = self._upload(fjobs, dev), len(fjobs)
         self.djobs, self.nd = self._upload(djobs, dev), len(djobs)
         self.ujobs, self.nu = self._upload(ujobs, dev), len(ujobs)
+
+    @staticmethod
+    def _assign(jobs, nblocks):
+        total = 0
+        for j in jobs:
+            j.first_block = total
+            total += nblocks(j)
+        return total
 
     @staticmethod
     def _pjob(w, out, cmap, L, mode, R, K, ttot):
@@ -156,15 +168,15 @@ class PackSet:
         return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
 
     def pack_forward(self):
-        _lib.call("bts_pack_weight_batch", C.c_void_p(self.fjobs.data_ptr()), self.nf, self.fmax, _lib.dtype_code(self.dtype),
+        _lib.call("bts_pack_weight_batch", C.c_void_p(self.fjobs.data_ptr()), self.nf, self.fblocks, _lib.dtype_code(self.dtype),
                   _lib.stream_ptr())
 
     def pack_dgrad(self):
-        _lib.call("bts_pack_weight_batch", C.c_void_p(self.djobs.data_ptr()), self.nd, self.dmax, _lib.dtype_code(self.dtype),
+        _lib.call("bts_pack_weight_batch", C.c_void_p(self.djobs.data_ptr()), self.nd, self.dblocks, _lib.dtype_code(self.dtype),
                   _lib.stream_ptr())
 
     def unpack_all(self, dwp_arena, gw_arena):
-        _lib.call("bts_unpack_wgrad_batch", C.c_void_p(self.ujobs.data_ptr()), self.nu, self.umax,
+        _lib.call("bts_unpack_wgrad_batch", C.c_void_p(self.ujobs.data_ptr()), self.nu, self.ublocks,
                   C.c_void_p(dwp_arena.data_ptr()), C.c_void_p(gw_arena.data_ptr()), _lib.stream_ptr())
 
 

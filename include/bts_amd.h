@@ -205,22 +205,26 @@ int bts_unpack_wgrad(const float* dwp, int Cout, int Cin, int KK, const int32_t*
                      const uint16_t* tapmask, float* gw, int accumulate, bts_stream_t stream);
 
 /* Multi-tensor forms of the two functions above: ONE launch for every layer of the decoder (the eager path would
- * otherwise issue ~130 tiny launches per step).  The job tables live on the DEVICE; field meanings as above. */
+ * otherwise issue ~130 tiny launches per step).  The job tables live on the DEVICE; field meanings as above.
+ * Jobs are sorted by first_block: job i owns blocks [first_block_i, first_block_{i+1}) of the launch, and needs
+ *   pack:   ceil(NCO/32) * ceil(NE/32) blocks with (NCO, NE) = (R, K) in mode 0 and (K, R) in mode 1,
+ *   unpack: ceil(Cout*Cin/256) blocks;
+ * total_blocks is the sum over the jobs. */
 typedef struct {
     const float* w; void* out; const int32_t* cmap;
     int32_t Cout, Cin, KK, mode, R, K, T;
     uint16_t tapmask[BTS_MAX_TAP];
-    int32_t pad_;
+    int32_t first_block;
 } bts_pack_job_t;
 typedef struct {
     int64_t dwp_off; int64_t gw_off;   /* element offsets into the dwp / gw arenas passed to the call */
     const int32_t* kinv;
     int32_t Cout, Cin, KK, K, T;
     uint16_t tapmask[BTS_MAX_TAP];
-    int32_t pad_;
+    int32_t first_block;
 } bts_unpack_job_t;
-int bts_pack_weight_batch(const bts_pack_job_t* jobs, int n_jobs, long max_elems, int dtype, bts_stream_t stream);
-int bts_unpack_wgrad_batch(const bts_unpack_job_t* jobs, int n_jobs, long max_elems, const float* dwp_base,
+int bts_pack_weight_batch(const bts_pack_job_t* jobs, int n_jobs, long total_blocks, int dtype, bts_stream_t stream);
+int bts_unpack_wgrad_batch(const bts_unpack_job_t* jobs, int n_jobs, long total_blocks, const float* dwp_base,
                            float* gw_base, bts_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

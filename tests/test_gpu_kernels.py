@@ -304,3 +304,30 @@ def test_lpg_chain_bwd_vs_autograd(c0, k, acc):
         ref_g = wi.grad.reshape(wi.shape[0], wi.shape[1])
         assert rel_l2(g[:, :wi.shape[1]], ref_g) < 2e-2 and rel(g[:, :wi.shape[1]], ref_g) < 5e-2
         assert g[:, wi.shape[1]:].abs().max().item() == 0.0 if g.shape[1] > wi.shape[1] else True
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_batched_pack_unpack_match_single_layer_kernels(dt):
+    """bts_pack_weight_batch / bts_unpack_wgrad_batch (one launch for every decoder layer, LDS-tiled) must reproduce
+    the per-layer bts_pack_weight / bts_unpack_wgrad bit for bit: forward operands, data-gradient operands of every
+    input segment, and the weight gradients scattered back to PyTorch layout (odd channel counts, phases, dilations)."""
+    from bts_amd.decoder import DecoderPlan, PackSet
+    feat, nf = [8, 24, 16, 40, 56], 128
+    plan = DecoderPlan(feat, nf)
+    gen = torch.Generator().manual_seed(11)
+    P = {k: v.to(DEV) for k, v in O.make_decoder_params(feat, nf, gen).items()}
+    ps = PackSet(plan, P, dt)
+    ps.pack_forward()
+    ps.pack_dgrad()
+    dwp = torch.randn(ps.dwp_total, generator=gen).to(DEV)
+    gw = torch.full((ps.gw_total,), float("nan"), device=DEV)
+    ps.unpack_all(dwp, gw)
+    for n, L in plan.layers.items():
+        w = P[n + ".weight"]
+        assert torch.equal(ps.fwd[n], L.pack_fwd(w, dt)), n
+        for i in range(len(L.seg_channels)):
+            assert torch.equal(ps.dgrad[(n, i)], L.pack_dgrad(w, dt, i)), (n, i)
+        off, shape = ps.dwp_off[n]
+        goff, gshape = ps.gw_off[n]
+        want = L.unpack_wgrad(dwp[off:off + shape[0] * shape[1] * shape[2]].view(shape), dt)
+        assert torch.equal(gw[goff:goff + want.numel()].view(gshape), want), n
