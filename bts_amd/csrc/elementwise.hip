@@ -26,13 +26,22 @@ __device__ __forceinline__ void thread_coords(int bx_log2, int& cv, long& p0, lo
     pstep = (long)gridDim.x * by;
 }
 
-static void pick_grid(long M, int CV, int& bx_log2, dim3& grid, int max_blocks = 4096) {
+// Grid for the pixel-strided elementwise kernels.  Every thread first loads its per-channel constants (up to 48
+// scalars for the BatchNorm backward), so it must own enough pixels to amortise that prologue: aim at >= 8 vectors
+// per thread, within [256, max_blocks] workgroups (one wave of workgroups per CU is enough to saturate HBM once each
+// thread keeps two iterations of loads in flight, see the `#pragma unroll 2` loops).
+static void pick_grid(long M, int CV, int& bx_log2, dim3& grid, int max_blocks = 2048, bool fixed = false) {
     bx_log2 = 0;
     while ((1 << bx_log2) < CV && bx_log2 < 5) ++bx_log2;
     const int bx = 1 << bx_log2, by = 256 >> bx_log2;
     const int gy = (CV + bx - 1) / bx;
     long gx = (M + by - 1) / by;
-    const long cap = max_blocks / gy > 0 ? max_blocks / gy : 1;
+    long blocks = max_blocks;
+    if (!fixed) {
+        const long want = (M * (long)gy * bx + 256l * 8 - 1) / (256l * 8);
+        blocks = want < 256 ? 256 : (want > max_blocks ? max_blocks : want);
+    }
+    const long cap = blocks / gy > 0 ? blocks / gy : 1;
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     grid = dim3((unsigned)gx, (unsigned)gy);
@@ -60,6 +69,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const void* __restrict_
     float sc[V], sh[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) { sc[e] = scale ? scale[cv * V + e] : 1.f; sh[e] = shift ? shift[cv * V + e] : 0.f; }
+#pragma unroll 2
     for (; p < s.M; p += ps) {
         float f[V];
         ldv<TX>(x, (size_t)p * xs + cv * V, f);
@@ -239,6 +249,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
         k0[e] = use_batch ? sums[c] * invM : 0.f;
         k1[e] = use_batch ? sums[C + c] * invM : 0.f;
     }
+#pragma unroll 2
     for (; p < s.M; p += ps) {
         float fx[V], fd[V], o[V];
         ldv<T>(x, (size_t)p * xs + cv * V, fx);
@@ -285,6 +296,7 @@ __global__ __launch_bounds__(256) void act_bwd_vec_kernel(const void* __restrict
     int cv; long p, ps;
     thread_coords(bxl, cv, p, ps, s);
     if (cv >= s.CV) return;
+#pragma unroll 2
     for (; p < s.M; p += ps) {
         float g[V], v[V];
         ldv<T>(dy, (size_t)p * dys + cv * V, g);
