@@ -970,6 +970,273 @@ __global__ __launch_bounds__(256) void conv_wgrad(const ConvK a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weight gradient of the narrow full-resolution 3x3 layers (conv1, conv2: Cout <= 64, K <= ~170; bf16) on a 2-D
+// pixel tile with an LDS halo -- the transpose of conv_halo.
+//
+//     dW[co][tap][ci] = sum_p dz[p][co] * X[p + tap][ci]        (contraction over PIXELS)
+//
+// MFMA wants the contracted index contiguous per lane (8 bf16 = 16 B), but NHWC keeps pixels strided.  The generic
+// conv_wgrad transposes every operand fragment in registers, per tap; here the (TH+2) x 34 input patch and the
+// TH x 32 dz tile are transposed ONCE per tile while they are written to LDS (ds_write_b16 scatter into
+// channel-major rows XT[ci][row][x], DT[co][row][x]; consecutive lanes = consecutive pixels = consecutive bytes, so
+// the scatter is bank-conflict free), and all nine taps then read their B fragments from the same XT rows at a
+// shifted pixel offset (row +-1: 80-byte row pitch; column +-1: a 2-byte shift of the 16-byte read -- gfx950 supports
+// unaligned ds_read_b128).  A workgroup owns 32 output channels x (32 TN) input channels, i.e. 9 TN accumulator
+// tiles dealt round-robin to its 4 waves, walks a contiguous range of tiles with the next tile's global loads in
+// flight under the MFMAs, and emits one set of atomics at the end.  grid = (tile workers, ci groups, co groups).
+// ------------------------------------------------------------------------------------------------
+typedef u32x4_t u32x4_unaligned_t __attribute__((aligned(2)));
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_halo(const ConvK a) {
+    constexpr int TH = 8, TW = 32, PW = TW + 2, NPIX = (TH + 2) * PW;     // patch pixels
+    constexpr int PROW = 80;                                               // bytes per patch row in XT (34 px, padded)
+    constexpr int XS = (TH + 2) * PROW + 16, DS = TH * 64 + 16;            // channel pitch of XT / DT (+16: bank skew)
+    constexpr int KVG = 4 * TN, CIG = 32 * TN;                             // 16-byte channel vectors / channels per ci group
+    constexpr int NIT = (NPIX * KVG + 255) / 256;                          // patch items (pixel, vector) per thread
+    constexpr int NTILE = 9 * TN, TPW = (NTILE + 3) / 4;                   // accumulator tiles: total / per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* XT = smem;
+    char* DT = smem + CIG * XS;
+    __shared__ const char* c_base[KVG];
+    __shared__ uint32_t c_sb[KVG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 31, fk = lane >> 5;
+    const int cig = blockIdx.y, cog = blockIdx.z;
+    if (tid < KVG) {
+        const int cv = cig * KVG + tid;
+        int seg, seg_end; const char* sp; uint32_t sb, coffB;
+        pick_seg_b(a, cv < a.KV ? cv : 0, 16, seg, sp, sb, coffB, seg_end);
+        c_base[tid] = cv < a.KV ? sp + coffB : nullptr;
+        c_sb[tid] = sb;
+    }
+    __syncthreads();
+    const int tiles_x = (a.Wg + TW - 1) / TW, tiles_y = (a.Hg + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * a.N;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
+    auto origin = [&](int tile, int& n, int& y0, int& x0) {
+        const int tx = tile % tiles_x, r1 = tile / tiles_x;
+        y0 = (r1 % tiles_y) * TH; n = r1 / tiles_y; x0 = tx * TW;
+    };
+    // per-item constants: (vector c, patch pixel) of item j; LDS scatter base
+    int it_c[NIT], it_py[NIT], it_pc[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int i = tid + 256 * j;
+        const int c = i / NPIX, pix = i - c * NPIX;
+        it_c[j] = i < NPIX * KVG ? c : -1;
+        it_py[j] = pix / PW;
+        it_pc[j] = pix - it_py[j] * PW;
+    }
+    const int dzy = tid >> 5, dzx = tid & 31;                              // dz pixel of this thread
+    const int co_vecs = (a.Cout + 7) >> 3;
+    u32x4_t xr[NIT], zr[4];
+    auto load_tile = [&](int tile) {
+        int n, y0, x0;
+        origin(tile, n, y0, x0);
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            u32x4_t v = {0, 0, 0, 0};
+            if (it_c[j] >= 0) {
+                const char* base = c_base[it_c[j]];
+                const int iy = y0 - 1 + it_py[j], ix = x0 - 1 + it_pc[j];
+                if (base && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx)
+                    v = *(const u32x4_t*)(base + (size_t)((uint32_t)((n * a.Hx + iy) * a.Wx + ix) * c_sb[it_c[j]]));
+            }
+            xr[j] = v;
+        }
+        const int oy = y0 + dzy, ox = x0 + dzx;
+        const bool ok = oy < a.Hg && ox < a.Wg;
+        const char* zp = a.dz + ((size_t)(n * a.Hy + oy) * a.Wy + ox) * a.dz_stride * 2 + cog * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x4_t v = {0, 0, 0, 0};
+            if (ok && cog * 4 + j < co_vecs) v = *(const u32x4_t*)(zp + j * 16);
+            zr[j] = v;
+        }
+    };
+    auto scatter8 = [&](char* dst, int pitch, const u32x4_t& v) {         // 8 channels of one pixel -> 8 channel rows
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            *(uint16_t*)(dst + e * pitch) = (e & 1) ? (uint16_t)(d[e >> 1] >> 16) : (uint16_t)(d[e >> 1] & 0xffffu);
+    };
+    auto scatter_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j)
+            if (it_c[j] >= 0) scatter8(XT + it_c[j] * 8 * XS + it_py[j] * PROW + it_pc[j] * 2, XS, xr[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) scatter8(DT + j * 8 * DS + dzy * 64 + dzx * 2, DS, zr[j]);
+    };
+    // accumulator tiles of this wave: idx = wave + 4 q -> (tap, tn)
+    int boff[TPW], t_tap[TPW], t_tn[TPW];
+    f32x16_t acc[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int idx = wave + 4 * q;
+        const int tap = idx / TN, tn = idx - tap * TN;
+        int dy = 0, dx = 0, ioy, iox;
+        if (idx < NTILE) decode_tap(a.taps[tap], dy, dx, ioy, iox);
+        t_tap[q] = idx < NTILE ? tap : -1;
+        t_tn[q] = tn;
+        boff[q] = (tn * 32 + frow) * XS + (1 + dy) * PROW + (1 + dx + 8 * fk) * 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    }
+    const char* arow = DT + frow * DS + fk * 16;
+    if (t_begin < t_end) load_tile(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        __syncthreads();                                   // every wave finished reading the previous tile
+        scatter_tile();
+        __syncthreads();
+        if (tile + 1 < t_end) load_tile(tile + 1);         // in flight under the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 2 * TH; ++ks) {              // 16 pixels per step: tile row ks>>1, half ks&1
+            const int y = ks >> 1, h = ks & 1;
+            const u32x4_t fa = *(const u32x4_t*)(arow + y * 64 + h * 32);
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                if (t_tap[q] < 0) continue;
+                const u32x4_t fb = *(const u32x4_unaligned_t*)(XT + boff[q] + y * PROW + h * 32);
+                Mma<BF16>::run(fa, fb, acc[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        if (t_tap[q] < 0) continue;
+        const int k = cig * CIG + t_tn[q] * 32 + frow;
+        if (k >= a.Ktot) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cog * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+            if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * a.Ttot + t_tap[q]) * a.Ktot + k, acc[q][r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of a ONE-output-channel radius-1 convolution (get_depth, bts.py:193: 32 -> 1 at full resolution).
+// With a single output channel the contraction is a correlation-reduce, not a GEMM:
+//     dW[t][k] = sum_q X[q][k] * dz[q - tap_t]
+// so every input vector (16 B = 8 bf16 / 4 f32 channels of one pixel) is read exactly once, multiplied by the <= 9
+// neighbouring dz scalars (dz tile + halo staged in LDS) and accumulated in registers; a workgroup walks a contiguous
+// range of 8 x 32 pixel tiles and emits one set of atomics at the end.  HBM-bound: X once + dz once (the MFMA kernel
+// above spends 32x the tile on a 1-of-32 useful output row and re-reads X per tap).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_c1(const ConvK a, int kvp_log2) {
+    constexpr int TH = 8, TW = 32, PW = TW + 2, V = T::kVec, ES = T::kBytes;
+    constexpr int PR = (TH + 2) * PW, NLD = (PR + 255) / 256;
+    __shared__ float sdz[2][PR];
+    __shared__ float red[4 * 16 * 9 * V];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KVP = 1 << kvp_log2;
+    const int cv = tid & (KVP - 1), pl = tid >> kvp_log2, NPL = 256 >> kvp_log2;
+    const bool kok = cv < a.KV;
+    int seg, seg_end; const char* sp; uint32_t sb, coffB;
+    pick_seg_b(a, kok ? cv : 0, V * ES, seg, sp, sb, coffB, seg_end);
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        int dy = 0, dx = 0, ioy, iox;
+        if (t < a.T) decode_tap(a.taps[t], dy, dx, ioy, iox);
+        toff[t] = (1 - dy) * PW + (1 - dx);
+    }
+    float acc[9][V];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[t][e] = 0.f;
+    const int tiles_x = (a.Wg + TW - 1) / TW, tiles_y = (a.Hg + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * a.N;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
+    auto origin = [&](int tile, int& n, int& y0, int& x0) {
+        const int tx = tile % tiles_x, r1 = tile / tiles_x;
+        y0 = (r1 % tiles_y) * TH; n = r1 / tiles_y; x0 = tx * TW;
+    };
+    // dz tile + halo of `tile` -> registers (zeros outside the image: that is the convolution's padding)
+    auto load_dz = [&](int tile, float (&g)[NLD]) {
+        int n, y0, x0;
+        origin(tile, n, y0, x0);
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j;
+            const int py = i / PW, px = i - py * PW;
+            const int oy = y0 - 1 + py, ox = x0 - 1 + px;
+            g[j] = 0.f;
+            if (i < PR && (unsigned)oy < (unsigned)a.Hg && (unsigned)ox < (unsigned)a.Wg)
+                g[j] = T::ld(a.dz, ((size_t)(n * a.Hy + oy) * a.Wy + ox) * a.dz_stride);
+        }
+    };
+    auto store_dz = [&](float* dst, const float (&g)[NLD]) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            if (tid + 256 * j < PR) dst[tid + 256 * j] = g[j];
+    };
+    float gnext[NLD];
+    if (t_begin < t_end) {
+        load_dz(t_begin, gnext);
+        store_dz(sdz[0], gnext);
+    }
+    __syncthreads();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int cur = (tile - t_begin) & 1;
+        int n, y0, x0;
+        origin(tile, n, y0, x0);
+        if (tile + 1 < t_end) load_dz(tile + 1, gnext);      // in flight under this tile's X loads and FMAs
+        if (kok) {
+#pragma unroll 4
+            for (int p = pl; p < TH * TW; p += NPL) {
+                const int qy = p / TW, qx = p - qy * TW;
+                const int iy = y0 + qy, ix = x0 + qx;
+                const bool ok = iy < a.Hx && ix < a.Wx;
+                float f[V];
+                u32x4_t raw = {0, 0, 0, 0};
+                if (ok) raw = *(const u32x4_t*)(sp + (size_t)((uint32_t)((n * a.Hx + iy) * a.Wx + ix) * sb) + coffB);
+                T::unpack(raw, f);
+                const float* gz = sdz[cur] + qy * PW + qx;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float g = gz[toff[t]];
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[t][e] += g * f[e];
+                }
+            }
+        }
+        if (tile + 1 < t_end) store_dz(sdz[cur ^ 1], gnext);
+        __syncthreads();            // next buffer complete; everyone is done reading `cur`
+    }
+    // lanes with the same channel vector -> one value per wave, then across the four waves, then atomics
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float v = acc[t][e];
+            for (int m = 32; m >= KVP; m >>= 1) v += __shfl_xor(v, m, 64);
+            acc[t][e] = v;
+        }
+    __syncthreads();
+    if (lane < KVP) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < V; ++e) red[((wave * 16 + lane) * 9 + t) * V + e] = acc[t][e];
+    }
+    __syncthreads();
+    for (int i = tid; i < KVP * 9 * V; i += 256) {
+        const int e = i % V, t = (i / V) % 9, c = i / (9 * V);
+        if (c < a.KV && t < a.T) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[((w * 16 + c) * 9 + t) * V + e];
+            atomicAdd(a.dw + (size_t)t * a.Ktot + c * V + e, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight packing / gradient unpacking
 // ------------------------------------------------------------------------------------------------
 struct PackK {
@@ -1249,6 +1516,24 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
     return BTS_OK;
 }
 
+// A/B switch for measurements: BTS_WGRAD_HALO=0 sends the narrow full-resolution layers through the split-K kernel
+static bool wgrad_halo_enabled() {
+    static const int v = [] {
+        const char* e = getenv("BTS_WGRAD_HALO");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return v != 0;
+}
+
+// A/B switch for measurements: BTS_WGRAD_C1=0 sends the one-output-channel layers through the MFMA kernel
+static bool wgrad_c1_enabled() {
+    static const int v = [] {
+        const char* e = getenv("BTS_WGRAD_C1");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return v != 0;
+}
+
 template <typename T>
 static int launch_wgrad(const ConvK& k0, hipStream_t st) {
     ConvK k = k0;
@@ -1269,6 +1554,35 @@ static int launch_wgrad(const ConvK& k0, hipStream_t st) {
     // tile by output shape [Cout x (taps*K)]: narrow column tiles for the tiny 1x1 layers of the reduction chains keep
     // the register count low (these launches are latency-bound: occupancy is what matters, r1 profile)
     const long cols = (long)k.T * k.Ktot;
+    if (k.Cout == 1 && k.halo_ok && k.nphase == 1 && k.T <= 9 && k.KV <= 16 && wgrad_c1_enabled()) {
+        int kvp_log2 = 0;
+        while ((1 << kvp_log2) < k.KV) ++kvp_log2;
+        const int ntiles = ceil_div(k.Wg, 32) * ceil_div(k.Hg, 8) * k.N;
+        hipLaunchKernelGGL(conv_wgrad_c1<T>, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, k, kvp_log2);
+        BTS_LAUNCH_CHECK();
+        return BTS_OK;
+    }
+    if (T::kBytes == 2 && k.halo_ok && k.nphase == 1 && k.T == 9 && k.Cout <= 64 && k.Cout > 1 && wgrad_halo_enabled()) {
+        const int ntiles = ceil_div(k.Wg, 32) * ceil_div(k.Hg, 8) * k.N;
+        if (ntiles >= 256) {                               // large maps only: small ones keep the split-K kernel (>= 1 tile per CU here)
+            const int tn = k.KV > 4 ? 2 : 1;
+            const int cigs = ceil_div(k.KV, 4 * tn), cogs = ceil_div(k.Cout, 32);
+            int workers = 512 / (cigs * cogs);
+            if (workers < 64) workers = 64;
+            if (workers > ntiles) workers = ntiles;
+            const int lds = 32 * tn * (10 * 80 + 16) + 32 * (8 * 64 + 16);
+            auto kern = tn == 2 ? conv_wgrad_halo<2> : conv_wgrad_halo<1>;
+            static int lds_set[3] = {0, 0, 0};
+            if (lds > 48 * 1024 && !lds_set[tn]) {
+                if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+                    return BTS_ERR_LAUNCH;
+                lds_set[tn] = 1;
+            }
+            hipLaunchKernelGGL(kern, dim3(workers, cigs, cogs), dim3(256), (size_t)lds, st, k);
+            BTS_LAUNCH_CHECK();
+            return BTS_OK;
+        }
+    }
     if (k.Cout > 64) go(conv_wgrad<T, 2, 2, 1, 2, 2>, 128, 128);
     else if (k.Cout > 32) {
         if (cols <= 64) go(conv_wgrad<T, 1, 1, 4, 2, 2>, 64, 64);

@@ -110,6 +110,11 @@ CONV_CASES = [
     ("c1x1_wide", 64, [72], 1, 1, False, (2, 6, 10)),
     ("c1x1_to3", 3, [8], 1, 1, False, (2, 5, 7)),
     ("c3x3_to1", 1, [16], 9, 1, False, (2, 8, 8)),
+    ("c3x3_to1_ragged", 1, [32, 8], 9, 1, False, (3, 11, 37)),
+    # >= 256 tiles of 8x32 pixels: the bf16 weight gradient takes the LDS-halo kernel (conv_wgrad_halo)
+    ("wg_halo_conv1like", 32, [32, 8], 9, 1, False, (8, 61, 125)),
+    ("wg_halo_conv2like", 64, [64, 96, 8], 9, 1, False, (8, 61, 125)),
+    ("wg_halo_1group", 24, [32], 9, 1, False, (8, 64, 128)),
     ("up_small", 16, [24], 9, 1, True, (2, 5, 6)),
     ("up_big", 72, [136], 9, 1, True, (1, 6, 9)),
     ("daspp6seg", 32, [16, 8, 8, 8, 8, 8], 9, 1, False, (1, 9, 11)),

@@ -125,7 +125,7 @@ def misc_cases(B, H, W, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--set", default="all", help="all | conv | lpg | misc")
+    ap.add_argument("--set", default="all", help="all | conv | fwd | narrow | lpg | chain | misc")
     a = ap.parse_args()
     bf, f32 = torch.bfloat16, torch.float32
     res = []
@@ -147,6 +147,12 @@ def main():
         res += conv_case("conv2", bf, 64, [64, 96, 1], 9, 1, False, B, 176, 608, a.iters, ("fwd",))
         res += conv_case("upconv1", bf, 32, [64], 9, 1, True, B, 176, 608, a.iters, ("fwd",))
         res += conv_case("conv1", bf, 32, [32, 4], 9, 1, False, B, 352, 1216, a.iters, ("fwd",))
+    if a.set == "narrow":   # full-resolution narrow layers: weight gradients
+        B = 8
+        res += conv_case("get_depth", bf, 1, [32], 9, 1, False, B, 352, 1216, a.iters, ("wgrad",))
+        res += conv_case("conv1", bf, 32, [32, 4], 9, 1, False, B, 352, 1216, a.iters, ("wgrad",))
+        res += conv_case("upconv1", bf, 32, [64], 9, 1, True, B, 176, 608, a.iters, ("wgrad",))
+        res += conv_case("conv2", bf, 64, [64, 96, 1], 9, 1, False, B, 176, 608, a.iters, ("wgrad",))
     if a.set in ("all", "lpg"):
         for k in (8, 4, 2):
             res += lpg_case(8, 352, 1216, k, a.iters)      # train shape (configs[2], per GPU)
