@@ -980,21 +980,24 @@ __global__ __launch_bounds__(256) void conv_wgrad(const ConvK a) {
 // TH x 32 dz tile are transposed ONCE per tile while they are written to LDS (ds_write_b16 scatter into
 // channel-major rows XT[ci][row][x], DT[co][row][x]; consecutive lanes = consecutive pixels = consecutive bytes, so
 // the scatter is bank-conflict free), and all nine taps then read their B fragments from the same XT rows at a
-// shifted pixel offset (row +-1: 80-byte row pitch; column +-1: a 2-byte shift of the 16-byte read -- gfx950 supports
-// unaligned ds_read_b128).  A workgroup owns 32 output channels x (32 TN) input channels, i.e. 9 TN accumulator
-// tiles dealt round-robin to its 4 waves, walks a contiguous range of tiles with the next tile's global loads in
-// flight under the MFMAs, and emits one set of atomics at the end.  grid = (tile workers, ci groups, co groups).
+// shifted pixel offset: row +-1 is the 80-byte row pitch; column +-1 is a 2-byte shift, which a wave resolves in
+// registers -- it owns the three dx taps of one tap row, reads columns x..x+9 once (one aligned ds_read_b128 + one
+// ds_read_b32) and funnel-shifts (v_alignbit) the dx = 0 / +1 fragments out of them (unaligned ds_read_b128 works on
+// gfx950 but measured 1.8x slower end to end).  A workgroup owns 32 output channels x (32 TN) input channels: 9 TN
+// accumulator tiles on 6 waves (3 tap rows x TN ci tiles, or 3 tap rows x 2 pixel-row halves for TN = 1), walks a
+// contiguous range of tiles with the next tile's global loads in flight under the MFMAs, and emits one set of atomics
+// at the end.  grid = (tile workers, ci groups, co groups).
 // ------------------------------------------------------------------------------------------------
-typedef u32x4_t u32x4_unaligned_t __attribute__((aligned(2)));
-
 template <int TN>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_halo(const ConvK a) {
+__global__ __launch_bounds__(384, 3) void conv_wgrad_halo(const ConvK a) {
+    constexpr int NTHR = 384;
     constexpr int TH = 8, TW = 32, PW = TW + 2, NPIX = (TH + 2) * PW;     // patch pixels
     constexpr int PROW = 80;                                               // bytes per patch row in XT (34 px, padded)
     constexpr int XS = (TH + 2) * PROW + 16, DS = TH * 64 + 16;            // channel pitch of XT / DT (+16: bank skew)
     constexpr int KVG = 4 * TN, CIG = 32 * TN;                             // 16-byte channel vectors / channels per ci group
-    constexpr int NIT = (NPIX * KVG + 255) / 256;                          // patch items (pixel, vector) per thread
-    constexpr int NTILE = 9 * TN, TPW = (NTILE + 3) / 4;                   // accumulator tiles: total / per wave
+    constexpr int NIT = (NPIX * KVG + NTHR - 1) / NTHR;                    // patch items (pixel, vector) per thread
+    constexpr int NZT = (TH * TW * 4 + NTHR - 1) / NTHR;                   // dz items per thread
+    constexpr int KSPLIT = 2 / TN;                                         // waves sharing one (dy, tn) split the pixel rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* XT = smem;
     char* DT = smem + CIG * XS;
@@ -1018,40 +1021,45 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo(const ConvK a) {
         const int tx = tile % tiles_x, r1 = tile / tiles_x;
         y0 = (r1 % tiles_y) * TH; n = r1 / tiles_y; x0 = tx * TW;
     };
-    // per-item constants: (vector c, patch pixel) of item j; LDS scatter base
-    int it_c[NIT], it_py[NIT], it_pc[NIT];
+    // per-item constants, packed: vector << 16 | patch row << 8 | patch column (-1: none).  Consecutive lanes hold
+    // consecutive pixels, so each ds_write_b16 of the scatter covers consecutive bytes of one channel row.
+    int it[NIT], zt[NZT];
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
-        const int i = tid + 256 * j;
+        const int i = tid + NTHR * j;
         const int c = i / NPIX, pix = i - c * NPIX;
-        it_c[j] = i < NPIX * KVG ? c : -1;
-        it_py[j] = pix / PW;
-        it_pc[j] = pix - it_py[j] * PW;
+        const int py = pix / PW, pc = pix - py * PW;
+        it[j] = i < NPIX * KVG ? (c << 16 | py << 8 | pc) : -1;
     }
-    const int dzy = tid >> 5, dzx = tid & 31;                              // dz pixel of this thread
+#pragma unroll
+    for (int j = 0; j < NZT; ++j) {
+        const int i = tid + NTHR * j;
+        zt[j] = i < TH * TW * 4 ? ((i >> 8) << 16 | (i & 255)) : -1;      // vector << 16 | pixel (row * 32 + x)
+    }
     const int co_vecs = (a.Cout + 7) >> 3;
-    u32x4_t xr[NIT], zr[4];
+    u32x4_t xr[NIT], zr[NZT];
     auto load_tile = [&](int tile) {
         int n, y0, x0;
         origin(tile, n, y0, x0);
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
             u32x4_t v = {0, 0, 0, 0};
-            if (it_c[j] >= 0) {
-                const char* base = c_base[it_c[j]];
-                const int iy = y0 - 1 + it_py[j], ix = x0 - 1 + it_pc[j];
+            if (it[j] >= 0) {
+                const int c = it[j] >> 16, py = (it[j] >> 8) & 255, pc = it[j] & 255;
+                const char* base = c_base[c];
+                const int iy = y0 - 1 + py, ix = x0 - 1 + pc;
                 if (base && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx)
-                    v = *(const u32x4_t*)(base + (size_t)((uint32_t)((n * a.Hx + iy) * a.Wx + ix) * c_sb[it_c[j]]));
+                    v = *(const u32x4_t*)(base + (size_t)((uint32_t)((n * a.Hx + iy) * a.Wx + ix) * c_sb[c]));
             }
             xr[j] = v;
         }
-        const int oy = y0 + dzy, ox = x0 + dzx;
-        const bool ok = oy < a.Hg && ox < a.Wg;
-        const char* zp = a.dz + ((size_t)(n * a.Hy + oy) * a.Wy + ox) * a.dz_stride * 2 + cog * 64;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NZT; ++j) {
             u32x4_t v = {0, 0, 0, 0};
-            if (ok && cog * 4 + j < co_vecs) v = *(const u32x4_t*)(zp + j * 16);
+            const int zc = zt[j] >> 16, zp = zt[j] & 255;
+            const int oy = y0 + (zp >> 5), ox = x0 + (zp & 31);
+            if (zt[j] >= 0 && oy < a.Hg && ox < a.Wg && cog * 4 + zc < co_vecs)
+                v = *(const u32x4_t*)(a.dz + ((size_t)(n * a.Hy + oy) * a.Wy + ox) * a.dz_stride * 2 + cog * 64 + zc * 16);
             zr[j] = v;
         }
     };
@@ -1061,29 +1069,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo(const ConvK a) {
         for (int e = 0; e < 8; ++e)
             *(uint16_t*)(dst + e * pitch) = (e & 1) ? (uint16_t)(d[e >> 1] >> 16) : (uint16_t)(d[e >> 1] & 0xffffu);
     };
+    // (An 8 x 8 in-register transpose on DPP + one ds_write_b128 per lane was measured 1.6x SLOWER than this scatter:
+    //  ~26 VALU per vector and the extra live registers cost more than the seven saved LDS writes.)
     auto scatter_tile = [&]() {
 #pragma unroll
-        for (int j = 0; j < NIT; ++j)
-            if (it_c[j] >= 0) scatter8(XT + it_c[j] * 8 * XS + it_py[j] * PROW + it_pc[j] * 2, XS, xr[j]);
+        for (int j = 0; j < NIT; ++j) {
+            const int c = it[j] >> 16, py = (it[j] >> 8) & 255, pc = it[j] & 255;
+            if (it[j] >= 0) scatter8(XT + c * 8 * XS + py * PROW + pc * 2, XS, xr[j]);
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) scatter8(DT + j * 8 * DS + dzy * 64 + dzx * 2, DS, zr[j]);
+        for (int j = 0; j < NZT; ++j) {
+            const int zc = zt[j] >> 16, zp = zt[j] & 255;
+            if (zt[j] >= 0) scatter8(DT + zc * 8 * DS + (zp >> 5) * 64 + (zp & 31) * 2, DS, zr[j]);
+        }
     };
-    // accumulator tiles of this wave: idx = wave + 4 q -> (tap, tn)
-    int boff[TPW], t_tap[TPW], t_tn[TPW];
-    f32x16_t acc[TPW];
+    // wave role: one tap row dy (all three dx) of one 32-channel ci tile; with TN = 1 two waves split the pixel rows
+    const int grp = wave % (3 * TN), ksh = wave / (3 * TN);
+    const int dyi = grp / TN, tn = grp - dyi * TN, dy = dyi - 1;
+    int tap_of[3] = {-1, -1, -1};                          // tap index of (dy, dx = -1, 0, +1)
+    for (int t = 0; t < a.T; ++t) {
+        int tdy, tdx, ioy, iox;
+        decode_tap(a.taps[t], tdy, tdx, ioy, iox);
+        if (tdy == dy) {
+            if (tdx == -1) tap_of[0] = t;
+            else if (tdx == 0) tap_of[1] = t;
+            else tap_of[2] = t;
+        }
+    }
+    f32x16_t acc[3];
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-        const int idx = wave + 4 * q;
-        const int tap = idx / TN, tn = idx - tap * TN;
-        int dy = 0, dx = 0, ioy, iox;
-        if (idx < NTILE) decode_tap(a.taps[tap], dy, dx, ioy, iox);
-        t_tap[q] = idx < NTILE ? tap : -1;
-        t_tn[q] = tn;
-        boff[q] = (tn * 32 + frow) * XS + (1 + dy) * PROW + (1 + dx + 8 * fk) * 2;
+    for (int q = 0; q < 3; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-    }
     const char* arow = DT + frow * DS + fk * 16;
+    const char* brow = XT + (tn * 32 + frow) * XS + (1 + dy) * PROW + fk * 16;       // patch column x (dx = -1): 16-byte aligned
+    constexpr int KS_PER = 2 * TH / KSPLIT;
     if (t_begin < t_end) load_tile(t_begin);
     for (int tile = t_begin; tile < t_end; ++tile) {
         __syncthreads();                                   // every wave finished reading the previous tile
@@ -1091,26 +1111,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_halo(const ConvK a) {
         __syncthreads();
         if (tile + 1 < t_end) load_tile(tile + 1);         // in flight under the MFMAs
 #pragma unroll
-        for (int ks = 0; ks < 2 * TH; ++ks) {              // 16 pixels per step: tile row ks>>1, half ks&1
+        for (int kk = 0; kk < KS_PER; ++kk) {              // 16 pixels per step: tile row ks>>1, half ks&1
+            const int ks = ksh * KS_PER + kk;
             const int y = ks >> 1, h = ks & 1;
             const u32x4_t fa = *(const u32x4_t*)(arow + y * 64 + h * 32);
-#pragma unroll
-            for (int q = 0; q < TPW; ++q) {
-                if (t_tap[q] < 0) continue;
-                const u32x4_t fb = *(const u32x4_unaligned_t*)(XT + boff[q] + y * PROW + h * 32);
-                Mma<BF16>::run(fa, fb, acc[q]);
-            }
+            const u32x4_t v = *(const u32x4_t*)(brow + y * PROW + h * 32);            // columns x .. x+7
+            const uint32_t w = *(const uint32_t*)(brow + y * PROW + h * 32 + 16);     // columns x+8, x+9
+            const u32x4_t b0 = {__builtin_amdgcn_alignbit(v.y, v.x, 16), __builtin_amdgcn_alignbit(v.z, v.y, 16),
+                                __builtin_amdgcn_alignbit(v.w, v.z, 16), __builtin_amdgcn_alignbit(w, v.w, 16)};
+            const u32x4_t bp = {v.y, v.z, v.w, w};
+            Mma<BF16>::run(fa, v, acc[0]);                 // dx = -1
+            Mma<BF16>::run(fa, b0, acc[1]);                // dx =  0: one pixel (2 bytes) further
+            Mma<BF16>::run(fa, bp, acc[2]);                // dx = +1
         }
     }
+    const int k = cig * CIG + tn * 32 + frow;
+    if (k < a.Ktot) {
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-        if (t_tap[q] < 0) continue;
-        const int k = cig * CIG + t_tn[q] * 32 + frow;
-        if (k >= a.Ktot) continue;
+        for (int q = 0; q < 3; ++q) {
+            if (tap_of[q] < 0) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = cog * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-            if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * a.Ttot + t_tap[q]) * a.Ktot + k, acc[q][r]);
+            for (int r = 0; r < 16; ++r) {
+                const int co = cog * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * a.Ttot + tap_of[q]) * a.Ktot + k, acc[q][r]);
+            }
         }
     }
 }
@@ -1578,7 +1602,7 @@ static int launch_wgrad(const ConvK& k0, hipStream_t st) {
                     return BTS_ERR_LAUNCH;
                 lds_set[tn] = 1;
             }
-            hipLaunchKernelGGL(kern, dim3(workers, cigs, cogs), dim3(256), (size_t)lds, st, k);
+            hipLaunchKernelGGL(kern, dim3(workers, cigs, cogs), dim3(384), (size_t)lds, st, k);
             BTS_LAUNCH_CHECK();
             return BTS_OK;
         }
