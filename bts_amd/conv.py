@@ -51,7 +51,7 @@ def _dn(dtype):
 
 
 def _tile(cout, M=0, nphase=1):      # mirrors launch_fwd() in csrc/conv_igemm.hip (LDS-DMA variants)
-    return "128x256" if cout > 64 else ("64x128" if cout > 32 else "32x256")
+    return "128x128" if cout > 64 else ("64x128" if cout > 32 else "32x256")
 
 
 def _wtile(cout):     # mirrors launch_wgrad()

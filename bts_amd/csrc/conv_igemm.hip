@@ -1517,8 +1517,12 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
     }
     if (use_lds_dma()) {
         // tile / pipeline depth by problem shape (LDS: NS * (BM+BN) * 128 B):
-        //   d  128co x 256px, 8 waves, 2 stages ( 96 KiB, 1 WG/CU = 2 waves/SIMD)  [r1: 594-644 TF on conv5/daspp_conv]
-        //   a  128co x 128px, 4 waves, 2 stages ( 64 KiB, 2 WG/CU)                  [r1: 553-592 TF]
+        //   a  128co x 128px, 4 waves, 2 stages ( 64 KiB, 2 WG/CU): default.  With the strength-reduced address path and
+        //      fragment read-ahead it beats d on every layer probed (conv5 725 vs 675 TF, conv3 527 vs 446, conv4 670 vs
+        //      601, daspp 3x3 546 vs 513): two independent workgroups per CU overlap DMA and MFMA phases better than one
+        //      8-wave workgroup, and the mid-size layers get 2x the workgroups (209 -> 418 tiles on 256 CUs).
+        //   d  128co x 256px, 8 waves, 2 stages ( 96 KiB, 1 WG/CU = 2 waves/SIMD)  [early r1, before those changes: 594-644 TF
+        //      on conv5/daspp_conv vs 553-592 for a]
         //   b  128co x 128px, 4 waves, 3 stages ( 96 KiB, 1 WG/CU = 1 wave/SIMD)   [r1: 339-368 TF: too few waves]
         //   c  128co x 256px, 8 waves, 3 stages (144 KiB)                           [r1: = d; depth is not the limiter]
         //   64co x 128px and 32co x 256px, 4 waves, 2 stages for narrow layers
