@@ -1139,6 +1139,176 @@ __global__ __launch_bounds__(384, 3) void conv_wgrad_halo(const ConvK a) {
     }
 }
 
+// Same idea for the sub-pixel up-convolutions (upconv1 / upconv2, bts.py:69-80: nearest x2 + 3x3 = 4 output phases
+// x 2x2 taps on the coarse input).  dz lives on the fine grid: the tile's 2 TH x 64 fine pixels are de-interleaved
+// into one DT[phase][co][row][x] image per phase while they are scattered; the coarse input patch XT is shared by
+// the four phases.  A role = (phase, tap row dy, ci tile) with its two dx taps (dx in {-1,0} or {0,+1}) funnel-shifted
+// out of one aligned read as above; 8 TN roles on 8 waves.
+template <int TN>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_halo_up(const ConvK a) {
+    constexpr int NTHR = 512;
+    constexpr int TH = 8, TW = 32, PW = TW + 2, NPIX = (TH + 2) * PW;
+    constexpr int PROW = 80;
+    constexpr int XS = (TH + 2) * PROW + 16, DS = TH * 64 + 16;
+    constexpr int KVG = 4 * TN, CIG = 32 * TN;
+    constexpr int NIT = (NPIX * KVG + NTHR - 1) / NTHR;
+    constexpr int NZT = (4 * TH * TW * 4) / NTHR;                          // 4096 dz items (fine pixel, co vector)
+    constexpr int RPW = TN;                                                // roles per wave (8 TN roles, 8 waves)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* XT = smem;
+    char* DT = smem + CIG * XS;                                            // [phase][32 co][TH][32] bf16, pitch DS per co
+    __shared__ const char* c_base[KVG];
+    __shared__ uint32_t c_sb[KVG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 31, fk = lane >> 5;
+    const int cig = blockIdx.y, cog = blockIdx.z;
+    if (tid < KVG) {
+        const int cv = cig * KVG + tid;
+        int seg, seg_end; const char* sp; uint32_t sb, coffB;
+        pick_seg_b(a, cv < a.KV ? cv : 0, 16, seg, sp, sb, coffB, seg_end);
+        c_base[tid] = cv < a.KV ? sp + coffB : nullptr;
+        c_sb[tid] = sb;
+    }
+    __syncthreads();
+    const int tiles_x = (a.Wg + TW - 1) / TW, tiles_y = (a.Hg + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * a.N;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
+    auto origin = [&](int tile, int& n, int& y0, int& x0) {
+        const int tx = tile % tiles_x, r1 = tile / tiles_x;
+        y0 = (r1 % tiles_y) * TH; n = r1 / tiles_y; x0 = tx * TW;
+    };
+    int it[NIT];                                           // vector << 16 | patch row << 8 | patch column (-1: none)
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int i = tid + NTHR * j;
+        const int c = i / NPIX, pix = i - c * NPIX;
+        const int py = pix / PW, pc = pix - py * PW;
+        it[j] = i < NPIX * KVG ? (c << 16 | py << 8 | pc) : -1;
+    }
+    const int co_vecs = (a.Cout + 7) >> 3;
+    u32x4_t xr[NIT], zr[NZT];
+    auto load_tile = [&](int tile) {
+        int n, y0, x0;
+        origin(tile, n, y0, x0);
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            u32x4_t v = {0, 0, 0, 0};
+            if (it[j] >= 0) {
+                const int c = it[j] >> 16, py = (it[j] >> 8) & 255, pc = it[j] & 255;
+                const char* base = c_base[c];
+                const int iy = y0 - 1 + py, ix = x0 - 1 + pc;
+                if (base && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx)
+                    v = *(const u32x4_t*)(base + (size_t)((uint32_t)((n * a.Hx + iy) * a.Wx + ix) * c_sb[c]));
+            }
+            xr[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NZT; ++j) {                    // item = tid + 512 j: co vector j >> 1, fine pixel (tid + 512 j) & 1023
+            const int fp = (tid + NTHR * j) & 1023, zc = (tid + NTHR * j) >> 10;
+            const int oy = 2 * y0 + (fp >> 6), ox = 2 * x0 + (fp & 63);
+            u32x4_t v = {0, 0, 0, 0};
+            if (oy < 2 * a.Hg && ox < 2 * a.Wg && cog * 4 + zc < co_vecs)
+                v = *(const u32x4_t*)(a.dz + ((size_t)(n * a.Hy + oy) * a.Wy + ox) * a.dz_stride * 2 + cog * 64 + zc * 16);
+            zr[j] = v;
+        }
+    };
+    auto scatter8 = [&](char* dst, int pitch, const u32x4_t& v) {
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            *(uint16_t*)(dst + e * pitch) = (e & 1) ? (uint16_t)(d[e >> 1] >> 16) : (uint16_t)(d[e >> 1] & 0xffffu);
+    };
+    auto scatter_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int c = it[j] >> 16, py = (it[j] >> 8) & 255, pc = it[j] & 255;
+            if (it[j] >= 0) scatter8(XT + c * 8 * XS + py * PROW + pc * 2, XS, xr[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NZT; ++j) {
+            const int fp = (tid + NTHR * j) & 1023, zc = (tid + NTHR * j) >> 10;
+            const int fy = fp >> 6, fx = fp & 63;
+            const int ph = (fy & 1) * 2 + (fx & 1);                        // output phase of this fine pixel (cf. conv_halo epilogue)
+            scatter8(DT + (ph * 32 + zc * 8) * DS + (fy >> 1) * 64 + (fx >> 1) * 2, DS, zr[j]);
+        }
+    };
+    // roles of this wave
+    int r_ph[RPW], r_tn[RPW], r_dy[RPW], r_dx0[RPW], r_tap[RPW][2];
+    f32x16_t acc[RPW][2];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int r = wave + 8 * q;
+        const int tn = r % TN, rr = r / TN, dysel = rr & 1, ph = rr >> 1;
+        // tap rows of this phase: smallest dy and the other one
+        int dmin = 2, dmax = -2;
+        for (int t = 0; t < a.T; ++t) {
+            int tdy, tdx, ioy, iox;
+            decode_tap(a.taps[ph * a.T + t], tdy, tdx, ioy, iox);
+            dmin = min(dmin, tdy); dmax = max(dmax, tdy);
+        }
+        const int dy = dysel ? dmax : dmin;
+        int xmin = 2;
+        r_tap[q][0] = r_tap[q][1] = -1;
+        for (int t = 0; t < a.T; ++t) {
+            int tdy, tdx, ioy, iox;
+            decode_tap(a.taps[ph * a.T + t], tdy, tdx, ioy, iox);
+            if (tdy == dy) xmin = min(xmin, tdx);
+        }
+        for (int t = 0; t < a.T; ++t) {
+            int tdy, tdx, ioy, iox;
+            decode_tap(a.taps[ph * a.T + t], tdy, tdx, ioy, iox);
+            if (tdy == dy && (dysel == 0 || dmax != dmin)) {
+                if (tdx == xmin) r_tap[q][0] = ph * a.T + t;
+                else if (tdx == xmin + 1) r_tap[q][1] = ph * a.T + t;
+            }
+        }
+        r_ph[q] = ph; r_tn[q] = tn; r_dy[q] = dy; r_dx0[q] = xmin;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[q][u][e] = 0.f;
+    }
+    if (t_begin < t_end) load_tile(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        __syncthreads();
+        scatter_tile();
+        __syncthreads();
+        if (tile + 1 < t_end) load_tile(tile + 1);
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const char* arow = DT + (r_ph[q] * 32 + frow) * DS + fk * 16;
+            const char* brow = XT + (r_tn[q] * 32 + frow) * XS + (1 + r_dy[q]) * PROW + fk * 16;
+            const bool left = r_dx0[q] < 0;                                // taps dx = -1, 0 (else 0, +1)
+#pragma unroll
+            for (int ks = 0; ks < 2 * TH; ++ks) {
+                const int y = ks >> 1, h = ks & 1;
+                const u32x4_t fa = *(const u32x4_t*)(arow + y * 64 + h * 32);
+                const u32x4_t v = *(const u32x4_t*)(brow + y * PROW + h * 32);
+                const uint32_t w = *(const uint32_t*)(brow + y * PROW + h * 32 + 16);
+                const u32x4_t b0 = {__builtin_amdgcn_alignbit(v.y, v.x, 16), __builtin_amdgcn_alignbit(v.z, v.y, 16),
+                                    __builtin_amdgcn_alignbit(v.w, v.z, 16), __builtin_amdgcn_alignbit(w, v.w, 16)};
+                const u32x4_t bp = {v.y, v.z, v.w, w};
+                if (left) { Mma<BF16>::run(fa, v, acc[q][0]); Mma<BF16>::run(fa, b0, acc[q][1]); }
+                else { Mma<BF16>::run(fa, b0, acc[q][0]); Mma<BF16>::run(fa, bp, acc[q][1]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int k = cig * CIG + r_tn[q] * 32 + frow;
+        if (k >= a.Ktot) continue;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (r_tap[q][u] < 0) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = cog * 32 + (e & 3) + 8 * (e >> 2) + 4 * fk;
+                if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * a.Ttot + r_tap[q][u]) * a.Ktot + k, acc[q][u][e]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Weight gradient of a ONE-output-channel radius-1 convolution (get_depth, bts.py:193: 32 -> 1 at full resolution).
 // With a single output channel the contraction is a correlation-reduce, not a GEMM:
@@ -1589,6 +1759,27 @@ static int launch_wgrad(const ConvK& k0, hipStream_t st) {
         hipLaunchKernelGGL(conv_wgrad_c1<T>, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, k, kvp_log2);
         BTS_LAUNCH_CHECK();
         return BTS_OK;
+    }
+    if (T::kBytes == 2 && k.halo_ok && k.nphase == 4 && k.T == 4 && k.Cout <= 64 && wgrad_halo_enabled()) {
+        const int ntiles = ceil_div(k.Wg, 32) * ceil_div(k.Hg, 8) * k.N;
+        if (ntiles >= 256) {
+            const int tn = k.KV > 4 ? 2 : 1;
+            const int cigs = ceil_div(k.KV, 4 * tn), cogs = ceil_div(k.Cout, 32);
+            int workers = 256 / (cigs * cogs);
+            if (workers < 32) workers = 32;
+            if (workers > ntiles) workers = ntiles;
+            const int lds = 32 * tn * (10 * 80 + 16) + 4 * 32 * (8 * 64 + 16);
+            auto kern = tn == 2 ? conv_wgrad_halo_up<2> : conv_wgrad_halo_up<1>;
+            static int lds_set[3] = {0, 0, 0};
+            if (!lds_set[tn]) {
+                if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+                    return BTS_ERR_LAUNCH;
+                lds_set[tn] = 1;
+            }
+            hipLaunchKernelGGL(kern, dim3(workers, cigs, cogs), dim3(512), (size_t)lds, st, k);
+            BTS_LAUNCH_CHECK();
+            return BTS_OK;
+        }
     }
     if (T::kBytes == 2 && k.halo_ok && k.nphase == 1 && k.T == 9 && k.Cout <= 64 && k.Cout > 1 && wgrad_halo_enabled()) {
         const int ntiles = ceil_div(k.Wg, 32) * ceil_div(k.Hg, 8) * k.N;

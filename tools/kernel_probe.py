@@ -162,6 +162,7 @@ def main():
         res += conv_case("conv1", bf, 32, [32, 4], 9, 1, False, B, 352, 1216, a.iters, ("wgrad",))
         res += conv_case("upconv1", bf, 32, [64], 9, 1, True, B, 176, 608, a.iters, ("wgrad",))
         res += conv_case("conv2", bf, 64, [64, 96, 1], 9, 1, False, B, 176, 608, a.iters, ("wgrad",))
+        res += conv_case("upconv2", bf, 64, [128], 9, 1, True, B, 88, 304, a.iters, ("wgrad",))
     if a.set in ("all", "lpg"):
         for k in (8, 4, 2):
             res += lpg_case(8, 352, 1216, k, a.iters)      # train shape (configs[2], per GPU)
