@@ -50,12 +50,24 @@ def _dn(dtype):
     return "f32" if dtype == torch.float32 else "bf16"
 
 
-def _tile(cout, M=0, nphase=1):      # mirrors launch_fwd() in csrc/conv_igemm.hip (LDS-DMA variants)
-    return "128x128" if cout > 64 else ("64x128" if cout > 32 else "32x256")
+def _cdiv(a, b):
+    return (a + b - 1) // b
 
 
-def _wtile(cout):     # mirrors launch_wgrad()
-    return "128x128" if cout > 64 else ("64x128k2" if cout > 32 else "32x128k4")
+def _fwd_kernel(dtype, cout, halo):
+    """Name of the kernel launch_fwd() (csrc/conv_igemm.hip) picks: profiler label = rocprofv3 kernel family."""
+    if halo and cout <= 64:
+        return "conv_halo<%s>" % _dn(dtype)
+    return "conv_igemm_dma<%s,%s>" % (_dn(dtype), "128x128" if cout > 64 else ("64x128" if cout > 32 else "32x256"))
+
+
+def _wgrad_kernel(dtype, cout, radius1, up, n, hg, wg):
+    """Mirrors launch_wgrad()."""
+    if radius1 and not up and cout == 1:
+        return "conv_wgrad_c1<%s>" % _dn(dtype)
+    if radius1 and cout <= 64 and dtype == torch.bfloat16 and _cdiv(wg, 32) * _cdiv(hg, 8) * n >= 256:
+        return "conv_wgrad_halo_up<bf16>" if up else "conv_wgrad_halo<bf16>"
+    return "conv_wgrad<%s,%s>" % (_dn(dtype), "128x128" if cout > 64 else ("64x128k2" if cout > 32 else "32x128k4"))
 
 
 class ConvLayer:
@@ -164,7 +176,7 @@ class ConvLayer:
         d.accumulate = 0
         if profiler.ACTIVE is not None:
             M = N * Hx * Wx
-            profiler.note("conv_igemm_dma<%s,%s>" % (_dn(dtype), _tile(self.cout, M, self.nphase)), "mfma",
+            profiler.note(_fwd_kernel(dtype, self.cout, self.kk == 9 and self.dil == 1), "mfma",
                           2.0 * M * self.nphase * self.T * self.cin * self.cout)
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return out
@@ -202,7 +214,7 @@ class ConvLayer:
         d.accumulate = int(accumulate)
         if profiler.ACTIVE is not None:
             cseg = self.seg_channels[seg_index]
-            profiler.note("conv_igemm_dma<%s,%s>" % (_dn(dtype), _tile(gx.shape[3], N * Hg * Wg, 1)), "mfma",
+            profiler.note(_fwd_kernel(dtype, gx.shape[3], self.kk == 9 and self.dil == 1 and not self.up), "mfma",
                           2.0 * N * Hg * Wg * len(self.taps) * cseg * self.cout)
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return gx
@@ -220,7 +232,7 @@ class ConvLayer:
         d.Hy, d.Wy = dz.shape[1], dz.shape[2]
         d.osc = 2 if self.up else 1
         if profiler.ACTIVE is not None:
-            profiler.note("conv_wgrad<%s,%s>" % (_dn(dtype), _wtile(self.cout)), "mfma",
+            profiler.note(_wgrad_kernel(dtype, self.cout, self.kk == 9 and self.dil == 1, self.up, N, Hx, Wx), "mfma",
                           2.0 * N * Hx * Wx * self.nphase * self.T * self.cin * self.cout)
         call("bts_conv_wgrad", C.byref(d), C.c_void_p(dz.data_ptr()), pix_stride(dz), C.c_void_p(dwp.data_ptr()), stream_ptr())
         return dwp
