@@ -1696,7 +1696,7 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
         //   b  128co x 128px, 4 waves, 3 stages ( 96 KiB, 1 WG/CU = 1 wave/SIMD)   [r1: 339-368 TF: too few waves]
         //   c  128co x 256px, 8 waves, 3 stages (144 KiB)                           [r1: = d; depth is not the limiter]
         //   64co x 128px and 32co x 256px, 4 waves, 2 stages for narrow layers
-        static const char big = [] { const char* e = getenv("BTS_CONV_BIG"); return e ? e[0] : 'd'; }();   // A/B knob (d = default)
+        static const char big = [] { const char* e = getenv("BTS_CONV_BIG"); return e ? e[0] : 'a'; }();   // A/B knob (a = default)
         if (k.Cout > 64) {
             if (big == 'b') go2(conv_igemm_dma<T, 2, 2, 2, 2, 3>, 128, 128, 256);
             else if (big == 'c') go2(conv_igemm_dma<T, 2, 4, 2, 2, 3>, 128, 256, 512);
