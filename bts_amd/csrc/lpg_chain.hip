@@ -265,6 +265,7 @@ int dispatch_chain(const ChainK& k, int c0, int same_first, int kup, hipStream_t
     CASE(128, 1, 8); CASE(128, 0, 4); CASE(64, 0, 2); CASE(32, 0, 1);      // bts_size 512 (bts.py:171, 178, 186, 190)
     CASE(64, 1, 8); CASE(64, 0, 4); CASE(32, 0, 2); CASE(16, 0, 1);        // bts_size 256
     CASE(32, 1, 8); CASE(32, 0, 4); CASE(16, 0, 2);                        // bts_size 128 (reduc1x1 there is 8->1: unfused)
+    CASE(64, 0, 8); CASE(32, 0, 8); CASE(16, 0, 8);                        // halving tails of reduc8x8 (training: wide prefix layer-wise)
 #undef CASE
     return BTS_ERR_UNSUPPORTED;
 }
@@ -621,6 +622,7 @@ extern "C" int bts_lpg_chain_bwd(const void* x, int dtype, int x_stride, int c0,
     CASE(64, 2); CASE(32, 1);               // bts_size 512: reduc2x2, reduc1x1 (bts.py:186, 190)
     CASE(64, 4); CASE(32, 2); CASE(16, 1);  // bts_size 256
     CASE(32, 4); CASE(16, 2);               // bts_size 128
+    CASE(64, 8); CASE(32, 8); CASE(16, 8);  // halving tails of reduc8x8 behind its layer-wise 128 -> 128 -> 64 prefix
 #undef CASE
     return BTS_ERR_UNSUPPORTED;
 }

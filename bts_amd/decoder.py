@@ -344,11 +344,12 @@ class DecoderRun:
             self.tape.append(bwd)
         return y
 
-    def _chain_pack(self, name, ws, with_t):
-        """Fragment buffers of a chain, repacked from the live weights on every pass (two gathers through cached
-        indices): nothing keyed on tensor versions, so in-place / graph-replayed optimizer updates are always seen."""
+    def _chain_pack(self, name, start, ws, with_t):
+        """Fragment buffers of the chain layers ws (= layers start.. of chain `name`), repacked from the live weights
+        on every pass (two gathers through cached indices): nothing keyed on tensor versions, so in-place /
+        graph-replayed optimizer updates are always seen."""
         cache = self.plan.chain_cache
-        key = (name, self.dtype)
+        key = (name, start, self.dtype)
         pk = cache.get(key)
         if pk is None or pk.idx_fwd.device != ws[0].device:
             pk = chain_mod.ChainPacker([(w.shape[0], w.shape[1]) for w in ws], self.dtype, ws[0].device)
@@ -356,18 +357,34 @@ class DecoderRun:
         return pk.pack(ws, with_t)
 
     def chain_fused(self, name, x, k):
-        """Whole reduction_1x1 chain (+ plane head + LPG for k > 1) in one kernel (csrc/lpg_chain.hip).  Without
-        recording: any instantiated shape.  With recording: only shapes that also have the fused recompute backward
-        (narrow bf16 chains); the forward then stores nothing but its input.  Returns None otherwise."""
+        """reduction_1x1 chain (+ plane head + LPG for k > 1) in one kernel (csrc/lpg_chain.hip).  Without recording:
+        the whole chain, any instantiated shape.  With recording: the longest halving tail that also has the fused
+        recompute backward (bf16, <= 64 channels) -- all of reduc2x2 / reduc1x1, and reduc8x8 / reduc4x4 behind their
+        128-channel layers, which run layer by layer; the fused part stores nothing but its input.  None if no
+        instantiation applies."""
         keys = self.plan.reduc[name]
         ws = [self.P[key + ".weight"] for key in keys]
-        c0, same = ws[0].shape[1], ws[0].shape[0] == ws[0].shape[1]
-        if not chain_mod.supported(c0, same, k) or x.t.shape[3] != c0:
-            return None
         train = self.record
-        if train and not (FUSED_CHAIN_BWD and chain_mod.bwd_supported(c0, same, k, self.dtype)):
+        start = None
+        for s0 in range(len(keys) - 1):
+            c0, same = ws[s0].shape[1], ws[s0].shape[0] == ws[s0].shape[1]
+            ok = chain_mod.supported(c0, same, k)
+            if train:
+                ok = ok and FUSED_CHAIN_BWD and chain_mod.bwd_supported(c0, same, k, self.dtype)
+            if ok:
+                start = s0
+                break
+            if not train:
+                break                                   # no-grad: whole chain or nothing
+        if start is None or (start == 0 and x.t.shape[3] != ws[0].shape[1]):
             return None
-        frags, frags_t = self._chain_pack(name, ws, train)
+        for key in keys[:start]:
+            x = self.conv(key, [x], ACT_ELU)                       # bts.py:101-105, the wide layers
+        keys, ws = keys[start:], ws[start:]
+        c0, same = ws[0].shape[1], ws[0].shape[0] == ws[0].shape[1]
+        if x.t.shape[3] != c0:
+            raise BtsAmdError("reduction chain %s: unexpected channel padding" % name)
+        frags, frags_t = self._chain_pack(name, start, ws, train)
         d = Act(chain_mod.chain_fwd(x.t, frags, c0, same, k, self.max_depth))
         if train:
             def bwd():

@@ -267,7 +267,7 @@ def test_layout_roundtrip_and_pack_maps():
         assert torch.equal(gm[s], g[..., s])
 
 
-@pytest.mark.parametrize("c0,k", [(64, 2), (32, 1), (16, 2), (64, 4), (16, 1), (32, 4)])
+@pytest.mark.parametrize("c0,k", [(64, 2), (32, 1), (16, 2), (64, 4), (16, 1), (32, 4), (64, 8), (16, 8)])
 @pytest.mark.parametrize("acc", [False, True])
 def test_lpg_chain_bwd_vs_autograd(c0, k, acc):
     """Fused recompute backward of a narrow reduction chain + head (csrc/lpg_chain.hip) against PyTorch autograd of
