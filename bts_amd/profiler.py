@@ -38,9 +38,9 @@ class Profiler:
         if lpg:
             tot = {"kind": "hbm", "ms": sum(v["ms"] for v in lpg.values()), "work": sum(v["work"] for v in lpg.values()),
                    "launches": sum(v["launches"] for v in lpg.values())}
-            # every LPG-head kernel of the step: plane head + LPG fwd/bwd (k = 8, 4) and the fused reduction-chain
-            # forward / recompute-backward kernels (k = 2, 1), priced against their algorithmic HBM bytes
-            out["roofline_lpg"] = self._roof(("lpg_head* (heads k=8,4; fused chains k=2,1; fwd+bwd)", tot), mfma_peak_tflops, hbm_peak_gbs)
+            # every LPG-head kernel of the step (fused reduction-chain + plane + LPG forward / recompute-backward,
+            # or the separate plane-head + LPG kernels where a chain runs layer-wise), against algorithmic HBM bytes
+            out["roofline_lpg"] = self._roof(("lpg_head* (reduction chain + plane + LPG, fwd+bwd, k=8,4,2,1)", tot), mfma_peak_tflops, hbm_peak_gbs)
         total_ms = sum(v["ms"] for v in fam.values())
         out["kernel_time_ms_per_step"] = {k: round(v["ms"] / steps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:12]}
         out["hip_kernels_ms_per_step"] = round(total_ms / steps, 3)
