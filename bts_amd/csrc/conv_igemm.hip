@@ -58,6 +58,7 @@ struct ConvK {
     float* dw;
     int n_col_tiles, nchunks, chunks_per_split;
     int halo_ok;   // every tap within radius 1 on an unscaled same-size input: eligible for conv_halo
+    int kmajor;    // conv_igemm_dma K order: 1 = channel chunk outer, taps inner (needs KV % 8 == 0); 0 = tap outer
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
         }
     }
     const int TKV = a.T * a.KV;
-    const int nchunks = (TKV + 7) >> 3;
+    const int nchunks = a.kmajor ? (a.KV >> 3) * a.T : (TKV + 7) >> 3;
     const char* zero = (const char*)kZeroPage;
     const char* wrow[RA];
 #pragma unroll
@@ -410,7 +411,63 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
     for (int i = 0; i < RA; ++i) srcA[i] = wrow[i] ? wrow[i] + (size_t)vec * (VEC * ES) : zero;
 #pragma unroll
     for (int i = 0; i < RB; ++i) srcB[i] = zero;
+    // K order.  Tap-major (kmajor = 0) walks all channels of tap 0, then tap 1, ...: between two taps that touch the
+    // same input lines a workgroup streams the whole channel extent (hundreds of KiB), and with ~64 workgroups per XCD
+    // the 4 MiB L2 cannot keep them: PMC showed 871 MB fetched for the 98 MB of daspp_conv (9x: once per tap).
+    // Channel-chunk-major (kmajor = 1) runs the T taps of one 64-channel chunk back to back, so the 3x3 neighbourhood
+    // re-reads hit L2 while the lines are still resident.  It needs a fresh (tap-dependent) source address every step
+    // instead of every KV/8 steps; the padding tests are precomputed as one bit per (row, tap).
+    uint32_t okbits[RB];
+    int kc_chunk = 0, kc_tap = 0, kc_wchunk = 0, kc_wtap = 0;
+    const char* kc_base = nullptr;
+    uint32_t kc_sb = 0;
+    const int wtap_stride = a.Ktot * ES;
+    if (a.kmajor) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) okbits[i] = 0;
+        for (int t = 0; t < a.T; ++t) {
+            int dy, dx, ioy, iox;
+            decode_tap(sTap[phase * a.T + t], dy, dx, ioy, iox);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const bool ok = (unsigned)(py[i] + dy) < (unsigned)a.Hg && (unsigned)(px[i] + dx) < (unsigned)a.Wg;
+                okbits[i] |= ok ? (1u << t) : 0u;
+            }
+        }
+    }
+    auto prep_kmajor = [&]() {
+        if (kc_chunk >= (a.KV >> 3)) {                 // past the end: the pipeline tail fetches the zero page
+#pragma unroll
+            for (int i = 0; i < RA; ++i) srcA[i] = zero;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) srcB[i] = zero;
+            return;
+        }
+        if (kc_tap == 0) {                             // next 64-channel chunk: segment lookup once per T steps
+            const int cvk = kc_chunk * 8 + vec;
+            int seg, seg_end; const char* sp; uint32_t sb, coffB;
+            pick_seg_b(a, cvk, VEC * ES, seg, sp, sb, coffB, seg_end);
+            if (seg != curseg) {
+                curseg = seg;
+#pragma unroll
+                for (int i = 0; i < RB; ++i) rowoff[i] = rowpix[i] * sb;
+            }
+            kc_base = sp + (long)coffB;
+            kc_sb = sb;
+            kc_wchunk = cvk * (VEC * ES);
+            kc_wtap = 0;
+        }
+        const int toff = sTapOff[phase * a.T + kc_tap];
+        const char* base = kc_base + (long)(toff * (int)kc_sb);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) srcA[i] = wrow[i] ? wrow[i] + (kc_wtap + kc_wchunk) : zero;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) srcB[i] = ((okbits[i] >> kc_tap) & 1u) ? base + rowoff[i] : zero;
+        kc_wtap += wtap_stride;
+        if (++kc_tap == a.T) { kc_tap = 0; ++kc_chunk; }
+    };
     auto prep_chunk = [&](int chunk) {
+        if (a.kmajor) { prep_kmajor(); return; }
         const int kv = chunk * 8 + vec;
         const bool kok = kv < TKV;
         if (chunk > 0) {
@@ -1686,6 +1743,9 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
         return BTS_OK;
     }
     if (use_lds_dma()) {
+        // K order (see conv_igemm_dma): channel-chunk-major whenever it costs no padding; BTS_CONV_KMAJOR=0 for A/B
+        static const int kmajor_on = [] { const char* e = getenv("BTS_CONV_KMAJOR"); return (e && e[0] == '0') ? 0 : 1; }();
+        k.kmajor = kmajor_on && k.T > 1 && k.nphase == 1 && (k.KV % 8) == 0;   // (sub-pixel up-convs measured 6 % slower with it)
         // tile / pipeline depth by problem shape (LDS: NS * (BM+BN) * 128 B):
         //   a  128co x 128px, 4 waves, 2 stages ( 64 KiB, 2 WG/CU): default.  With the strength-reduced address path and
         //      fragment read-ahead it beats d on every layer probed (conv5 725 vs 675 TF, conv3 527 vs 446, conv4 670 vs

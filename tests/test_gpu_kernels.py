@@ -121,6 +121,11 @@ CONV_CASES = [
     ("up_small", 16, [24], 9, 1, True, (2, 5, 6)),
     ("up_big", 72, [136], 9, 1, True, (1, 6, 9)),
     ("daspp6seg", 32, [16, 8, 8, 8, 8, 8], 9, 1, False, (1, 9, 11)),
+    # channel counts that are multiples of 64: conv_igemm_dma runs channel-chunk-major (taps inner)
+    ("kmajor_2seg", 136, [64, 64], 9, 1, False, (1, 12, 20)),
+    ("kmajor_dil", 72, [128], 9, 6, False, (2, 10, 14)),
+    ("kmajor_up", 72, [128], 9, 1, True, (1, 6, 9)),
+    ("kmajor_3seg_wide", 130, [64, 128, 64], 9, 1, False, (2, 7, 9)),
 ]
 
 

@@ -156,6 +156,16 @@ def main():
         res += conv_case("conv5", bf, 512, [512, 384], 9, 1, False, B, 22, 76, a.iters, ("fwd",))
         res += conv_case("conv3", bf, 128, [128, 96, 1], 9, 1, False, B, 88, 304, a.iters, ("fwd", "dgrad"))
         res += conv_case("daspp_conv", bf, 128, [256, 128, 128, 128, 128, 128], 9, 1, False, B, 44, 152, a.iters, ("fwd",))
+    if a.set == "pmc":      # compact set for the HBM-traffic counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
+        B = 8
+        res += conv_case("conv5", bf, 512, [512, 384], 9, 1, False, B, 22, 76, a.iters, ("fwd", "wgrad"))
+        res += conv_case("daspp_conv", bf, 128, [256, 128, 128, 128, 128, 128], 9, 1, False, B, 44, 152, a.iters, ("fwd",))
+        res += conv_case("conv3", bf, 128, [128, 96, 1], 9, 1, False, B, 88, 304, a.iters, ("fwd", "dgrad"))
+        res += conv_case("conv2", bf, 64, [64, 96, 1], 9, 1, False, B, 176, 608, a.iters, ("fwd", "wgrad"))
+        res += conv_case("upconv1", bf, 32, [64], 9, 1, True, B, 176, 608, a.iters, ("fwd", "wgrad"))
+        res += conv_case("conv1", bf, 32, [32, 4], 9, 1, False, B, 352, 1216, a.iters, ("fwd", "wgrad"))
+        res += conv_case("get_depth", bf, 1, [32], 9, 1, False, B, 352, 1216, a.iters, ("wgrad",))
+        res += chain_cases(8, 352, 1216, bf, a.iters)
     if a.set == "narrow":   # full-resolution narrow layers: weight gradients
         B = 8
         res += conv_case("get_depth", bf, 1, [32], 9, 1, False, B, 352, 1216, a.iters, ("wgrad",))
