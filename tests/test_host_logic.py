@@ -1,0 +1,102 @@
+"""Host-side logic of the HIP path that can be checked without a GPU: weight-fragment packing indices, the block
+ranges of the batched pack / unpack launches, the decoder plan, and the profiler's kernel labels."""
+import pytest
+import torch
+
+from oracle import bts_oracle as O
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dims", [[64, 32, 16, 8, 3], [32, 16, 8, 1], [128, 128, 64, 32, 16, 8, 3], [16, 8, 3]])
+def test_chain_packer_matches_per_layer_packing(dims, dt):
+    """ChainPacker (two gathers through cached indices, used every training step) == layer-by-layer fragment packing,
+    for the forward fragments and for the W^T fragments of the recompute backward."""
+    from bts_amd import chain
+    gen = torch.Generator().manual_seed(len(dims))
+    ws = [torch.randn(dims[i + 1], dims[i], 1, 1, generator=gen) for i in range(len(dims) - 1)]
+    pk = chain.ChainPacker([(w.shape[0], w.shape[1]) for w in ws], dt, "cpu")
+    f, t = pk.pack(ws, True)
+    assert torch.equal(f, chain.pack_chain(ws, dt))
+    assert torch.equal(t, chain.pack_chain_t(ws, dt))
+    assert f.numel() % 1024 == 0 and t.numel() % 1024 == 0          # whole 64-lane x 16-byte fragments
+    f2, t2 = pk.pack(ws, False)
+    assert t2 is None and torch.equal(f, f2)
+
+
+def test_chain_fragment_orders():
+    """Layer 0 uses the natural K order (B operand from memory), later layers the MFMA accumulator order
+    k = 16 s + {0,1,2,3,8,9,10,11}[e] + 4 g (include/bts_amd.h, csrc/lpg_chain.hip header)."""
+    from bts_amd import chain
+    w = torch.arange(32 * 32, dtype=torch.float32).reshape(32, 32)         # w[row][k] = 32 row + k
+    first = chain._pack_layer(w, torch.float32, True).view(torch.float32).reshape(1, 4, 64, 4)
+    later = chain._pack_layer(w, torch.bfloat16, False).view(torch.bfloat16).float().reshape(1, 2, 64, 8)
+    lane = 37                                                               # row 5, g = 1
+    assert first[0, 2, lane].tolist() == [32 * 5 + 8 * 2 + 4 + j for j in range(4)]
+    assert later[0, 1, lane].tolist() == [32 * 5 + 16 + 4 + p for p in (0, 1, 2, 3, 8, 9, 10, 11)]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_packset_block_ranges(dt):
+    """Jobs of the batched pack / unpack launches own contiguous, non-overlapping block ranges whose sizes follow the
+    rule in include/bts_amd.h (32x32 tiles; 256 (co, ci) pairs)."""
+    from bts_amd import _lib
+    from bts_amd.decoder import DecoderPlan, PackSet
+    feat, nf = [96, 96, 192, 384, 2208], 512
+    plan = DecoderPlan(feat, nf)
+    P = {k: torch.empty(s) for k, s in ((n, sh) for n, sh in _param_shapes(feat, nf))}
+    ps = PackSet(plan, P, dt)
+
+    def jobs(buf, cls, n):
+        raw = bytes(buf.numpy().tobytes())
+        sz = len(raw) // n
+        assert sz == __import__("ctypes").sizeof(cls)
+        return [cls.from_buffer_copy(raw[i * sz:(i + 1) * sz]) for i in range(n)]
+
+    cdiv = lambda a, b: (a + b - 1) // b
+    for buf, n, total in ((ps.fjobs, ps.nf, ps.fblocks), (ps.djobs, ps.nd, ps.dblocks)):
+        js = jobs(buf, _lib.PackJob, n)
+        nxt = 0
+        for j in js:
+            assert j.first_block == nxt
+            nco, ne = (j.R, j.K) if j.mode == 0 else (j.K, j.R)
+            nxt += cdiv(nco, 32) * cdiv(ne, 32)
+        assert nxt == total
+    js = jobs(ps.ujobs, _lib.UnpackJob, ps.nu)
+    nxt = 0
+    for j in js:
+        assert j.first_block == nxt
+        nxt += cdiv(j.Cout * j.Cin, 256)
+    assert nxt == ps.ublocks
+    assert ps.gw_total == sum(v.numel() for k, v in P.items() if k.endswith(".weight") and v.dim() == 4)
+
+
+def _param_shapes(feat, nf):
+    gen = torch.Generator().manual_seed(0)
+    return [(k, tuple(v.shape)) for k, v in O.make_decoder_params(feat, nf, gen).items()]
+
+
+def test_decoder_plan_matches_reference_layer_list():
+    """40 convolutions, the reduction chains of bts.py:83-108 with the channel halving down to 8."""
+    from bts_amd.decoder import DecoderPlan
+    plan = DecoderPlan([96, 96, 192, 384, 2208], 512)
+    assert len(plan.layers) == 40
+    assert [plan.layers[k].cin for k in plan.reduc["reduc8x8"]] == [128, 128, 64, 32, 16, 8]
+    assert [plan.layers[k].cout for k in plan.reduc["reduc8x8"]] == [128, 64, 32, 16, 8, 3]
+    assert [plan.layers[k].cout for k in plan.reduc["reduc1x1"]] == [16, 8, 1]
+    assert plan.layers["upconv5.conv"].nphase == 4 and plan.layers["upconv5.conv"].T == 4      # sub-pixel phases
+    assert plan.layers["daspp_24.atrous_conv.aconv_sequence.4"].dil == 24
+
+
+def test_profiler_labels_follow_dispatch():
+    """Labels used for `roofline` must name the kernel family launch_fwd()/launch_wgrad() pick."""
+    from bts_amd import conv
+    bf, f32 = torch.bfloat16, torch.float32
+    assert conv._fwd_kernel(bf, 512, True) == "conv_igemm_dma<bf16,128x128>"
+    assert conv._fwd_kernel(bf, 32, True) == "conv_halo<bf16>"
+    assert conv._fwd_kernel(bf, 32, False) == "conv_igemm_dma<bf16,32x256>"
+    assert conv._wgrad_kernel(bf, 1, True, False, 8, 352, 1216) == "conv_wgrad_c1<bf16>"
+    assert conv._wgrad_kernel(bf, 32, True, False, 8, 352, 1216) == "conv_wgrad_halo<bf16>"
+    assert conv._wgrad_kernel(bf, 32, True, True, 8, 176, 608) == "conv_wgrad_halo_up<bf16>"
+    assert conv._wgrad_kernel(f32, 32, True, False, 8, 352, 1216) == "conv_wgrad<f32,32x128k4>"
+    assert conv._wgrad_kernel(bf, 32, True, False, 1, 32, 64) == "conv_wgrad<bf16,32x128k4>"      # < 256 tiles
+    assert conv._wgrad_kernel(bf, 512, True, False, 8, 22, 76) == "conv_wgrad<bf16,128x128>"
