@@ -69,6 +69,9 @@ SIGNATURES = {
     "bts_lpg_chain_bwd": [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _l, _i, _i, _i, _f, _p],
     "bts_pack_maps": [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "bts_unpack_maps": [_p, _i, _i, _p, _p, _i, _i, _i, _i, _p],
+    "bts_eval_workspace_bytes": [_i],
+    "bts_eval_errors": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i, _p, _p, _p, _p],
+    "bts_depth_to_u16": [_p, _p, _l, _f, _p],
     "bts_silog_workspace_bytes": [_l],
     "bts_silog_fwd": [_p, _p, _p, _f, _l, _f, _p, _p, _p, _p],
     "bts_silog_bwd": [_p, _p, _p, _f, _l, _f, _p, _p, _p, _p, _p],
@@ -90,7 +93,7 @@ SIGNATURES = {
     "bts_add_to": [_p, _i, _i, _p, _i, _i, _l, _i, _i, _p],
     "bts_adamw_step": [_p, _p, _p, _p, _p, _i, _l, _f, _f, _f, _f, _f, _f, _f, _p, _p],
 }
-_LONG_RET = {"bts_silog_workspace_bytes", "bts_bn_stats_workspace_bytes"}
+_LONG_RET = {"bts_silog_workspace_bytes", "bts_bn_stats_workspace_bytes", "bts_eval_workspace_bytes"}
 _NO_CHECK = _LONG_RET | {"bts_abi_version", "bts_current_device"}
 
 _lib = None

@@ -1801,7 +1801,8 @@ static int launch_wgrad(const ConvK& k0, hipStream_t st) {
         k.n_col_tiles = ceil_div((long)k.T * k.Ktot, BN);
         k.nchunks = ceil_div(k.M, PK);
         const int tiles = k.n_co_tiles * k.n_col_tiles * k.nphase;
-        int splits = ceil_div(1024, tiles);
+        static const int split_target = [] { const char* e = getenv("BTS_WGRAD_WGS"); return e ? atoi(e) : 1024; }();   // A/B knob
+        int splits = ceil_div(split_target, tiles);
         if (splits > k.nchunks) splits = k.nchunks;
         if (splits < 1) splits = 1;
         k.chunks_per_split = ceil_div(k.nchunks, splits);

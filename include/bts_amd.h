@@ -273,6 +273,27 @@ int bts_act_bwd(const void* dy, int dy_dtype, int dy_stride, const void* y, int 
 int bts_add_to(const void* x, int x_dtype, int x_stride, void* y, int y_dtype, int y_stride, long M, int C,
                int accumulate, bts_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------
+ * Evaluation / inference output
+ * bts_eval_errors replaces the per-image host loop of online_eval() (pytorch/bts_main.py:263-299): the kb-crop
+ * paste-back (:268-274: pred [B][pred_h][pred_w] sits at (top_margin, left_margin) of a zero canvas of the gt size),
+ * clamping to [min_depth, max_depth] with inf -> max, nan -> min (:276-279), validity gt in (min, max) (:281) inside
+ * the evaluation crop window [crop_y0, crop_y1) x [crop_x0, crop_x1) (garg / eigen crop, :283-295; pass the full image
+ * for no crop), and compute_errors (:143-165).  Outputs (either may be NULL, not both):
+ *   measures       [batch][9] f32  = [silog, abs_rel, log10, rms, sq_rel, log_rms, d1, d2, d3] per image
+ *   eval_measures  [10] f32, ACCUMULATED: [0..8] += measures of every image with >= 1 valid pixel, [9] += 1 per such
+ *                  image (:298-299) -- the tensor the reference all-reduces at :301-303.
+ * has_valid_depth [batch] bytes or NULL (:258-261: images without ground truth are skipped).
+ * workspace: bts_eval_workspace_bytes(batch), 8-byte aligned.  Sums are accumulated in f64 (numpy: pairwise f32). */
+long bts_eval_workspace_bytes(int batch);
+int bts_eval_errors(const float* pred, const float* gt, const uint8_t* has_valid_depth, int batch, int pred_h,
+                    int pred_w, int gt_h, int gt_w, int top_margin, int left_margin, float min_depth,
+                    float max_depth, int crop_y0, int crop_y1, int crop_x0, int crop_x1, void* workspace,
+                    float* measures, float* eval_measures, bts_stream_t stream);
+/* 16-bit PNG payload of bts_test.py:179-185: out[i] = (uint16) trunc(depth[i] * scale), scale = 256 (kitti) or 1000
+ * (nyu); saturates at 0 / 65535 (numpy leaves out-of-range casts undefined), nan -> 0. */
+int bts_depth_to_u16(const float* depth, uint16_t* out, long n, float scale, bts_stream_t stream);
+
 /* Fused multi-tensor AdamW step (torch.optim.AdamW semantics, bts_main.py:371-373, 456-460) over a
  * flat list of f32 tensors: the pointer arrays and `sizes` live on the DEVICE.  bias_c1/2 = 1 - beta^t.
  * If dev_hyper != NULL, {lr, bias_c1, bias_c2} are read from dev_hyper[0..2] on the device instead of the

@@ -344,3 +344,48 @@ def test_batched_pack_unpack_match_single_layer_kernels(dt):
         goff, gshape = ps.gw_off[n]
         want = L.unpack_wgrad(dwp[off:off + shape[0] * shape[1] * shape[2]].view(shape), dt)
         assert torch.equal(gw[goff:goff + want.numel()].view(gshape), want), n
+
+
+@pytest.mark.parametrize("tag", ["kitti", "nyu"])
+def test_eval_errors_vs_reference_golden(golden_dir, tag):
+    """bts_eval_errors (one device reduction per batch) against the reference's compute_errors on the same seeded maps
+    (tests/golden/eval.npz), through online_eval's paste-back / clamp / crop semantics; a batch of 3 with one image
+    flagged has_valid_depth = 0 and one all-invalid image checks the eval_measures accumulation (bts_main.py:258-299).
+    Tolerance 2e-5 relative: sums are f64 here, pairwise f32 in numpy; log / log10 differ by <= 2 ulp."""
+    import numpy as np
+    from bts_amd import evalops
+    from oracle import eval_oracle as E
+    g = np.load("%s/eval.npz" % golden_dir)
+    gh, gw, ph, pw, md, kb, garg, eig, ds = E.EVAL_CASES[tag]
+    pred, gt = E.synth_eval_case(tag)
+    want = g[tag + "_measures"]
+    P = torch.tensor(np.stack([pred, pred * 1.1, pred])).to(DEV)
+    G = torch.tensor(np.stack([gt, gt, np.zeros_like(gt)])).to(DEV)          # image 2: no valid ground truth at all
+    acc = torch.tensor([1.0] * 9 + [2.0], device=DEV)
+    m = evalops.compute_errors(P.unsqueeze(1), G.unsqueeze(1), 1e-3, md, ds, kb, garg, eig, eval_measures=acc)
+    got = m[0].double().cpu().numpy()
+    assert np.all(np.abs(got - want) <= 2e-5 * np.abs(want) + 1e-7), (got, want)
+    pf, valid = E.eval_prepare(pred * np.float32(1.1), gt, 1e-3, md, ds, kb, garg, eig)
+    want1 = np.array(E.compute_errors(gt[valid], pf[valid]), dtype=np.float64)
+    assert np.all(np.abs(m[1].double().cpu().numpy() - want1) <= 2e-5 * np.abs(want1) + 1e-7)
+    assert m[2].abs().max().item() == 0.0
+    exp = np.concatenate([1.0 + want + want1, [4.0]])                        # two images counted, the empty one skipped
+    assert np.all(np.abs(acc.double().cpu().numpy() - exp) <= 3e-5 * np.abs(exp))
+    acc2 = torch.zeros(10, device=DEV)
+    evalops.compute_errors(P, G, 1e-3, md, ds, kb, garg, eig, has_valid_depth=torch.tensor([0, 1, 1]), eval_measures=acc2)
+    assert acc2[9].item() == 1.0 and abs(acc2[1].item() - want1[1]) <= 3e-5 * want1[1]
+
+
+def test_depth_to_uint16_bit_exact():
+    """bts_test.py:179-185 payload: bit-exact against numpy on in-range values (kitti x256 over 352x1216, nyu x1000)."""
+    import numpy as np
+    from bts_amd import evalops
+    from oracle import eval_oracle as E
+    rng = np.random.RandomState(3)
+    for ds, md, shape in (("kitti", 80.0, (2, 1, 352, 1216)), ("nyu", 10.0, (3, 1, 37, 53))):
+        d = rng.uniform(1e-3, md, size=shape).astype(np.float32)
+        d.flat[:4] = [0.0, 1.0 / 256, md, 0.99999994]
+        out = evalops.depth_to_uint16(torch.tensor(d).to(DEV), ds).cpu().numpy()
+        assert out.dtype == np.uint16 and np.array_equal(out, E.depth_to_uint16(d, ds))
+    edge = torch.tensor([float("nan"), -1.0, 1e9, float("inf")], device=DEV)
+    assert evalops.depth_to_uint16(edge, "kitti").cpu().tolist() == [0, 0, 65535, 65535]

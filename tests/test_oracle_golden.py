@@ -151,3 +151,30 @@ def test_c_oracle_silog_matches_reference_golden(golden_dir):
     v = lib.silog_c(est.ctypes.data_as(fp), gt.ctypes.data_as(fp), mask.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)),
                     ctypes.c_long(est.size), ctypes.c_double(float(g["kitti_vf"])))
     assert abs(v - float(g["kitti_loss"])) / float(g["kitti_loss"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["kitti", "nyu"])
+def test_eval_oracle_matches_reference_compute_errors(golden_dir, tag):
+    """oracle/eval_oracle.py vs the reference's own compute_errors (bts_main.py:143-165; golden written by executing the
+    function's source from the unmodified file) on the masked pixel lists online_eval() would build."""
+    import numpy as np
+    from oracle import eval_oracle as E
+    g = np.load("%s/eval.npz" % golden_dir)
+    gh, gw, ph, pw, md, kb, garg, eig, ds = E.EVAL_CASES[tag]
+    pred, gt = E.synth_eval_case(tag)
+    chk = g[tag + "_checksum"]
+    assert abs(float(pred[np.isfinite(pred)].astype(np.float64).sum()) - chk[0]) <= 1e-9 * abs(chk[0])      # same inputs as the generator
+    assert abs(float(gt.astype(np.float64).sum()) - chk[1]) <= 1e-9 * abs(chk[1])
+    pf, valid = E.eval_prepare(pred, gt, 1e-3, md, ds, kb, garg, eig)
+    assert int(valid.sum()) == int(g[tag + "_nvalid"])
+    assert np.isfinite(pf).all() and pf.min() >= np.float32(1e-3) and pf.max() <= md
+    m = np.array(E.compute_errors(gt[valid], pf[valid]), dtype=np.float64)
+    assert np.array_equal(m, g[tag + "_measures"])                   # same numpy ops in the same order: bit-identical
+
+
+def test_eval_oracle_uint16_payload():
+    import numpy as np
+    from oracle import eval_oracle as E
+    d = np.array([[0.0, 0.0039, 1.0, 79.999, 80.0]], dtype=np.float32)
+    assert E.depth_to_uint16(d, "kitti").tolist() == [[0, 0, 256, 20479, 20480]]
+    assert E.depth_to_uint16(d[:, :3], "nyu").tolist() == [[0, 3, 1000]]

@@ -119,6 +119,17 @@ def misc_cases(B, H, W, iters):
     sc = torch.rand(64, device=DEV)
     t = timeit(lambda: ops.affine_act(x, sc, sc, ACT_RELU), iters)
     out.append(dict(case="affine_relu bf16 C=64", sec=t, alg_gbs=x.numel() * 4 / t / 1e9))
+    # evaluation side: online_eval metrics of a kitti batch (kb crop + garg crop), uint16 payload
+    from bts_amd import evalops
+    gtf = torch.rand(B, 1, 375, 1242, device=DEV) * 80
+    acc = torch.zeros(10, device=DEV)
+    t = timeit(lambda: evalops.compute_errors(est, gtf, 1e-3, 80.0, "kitti", True, True, False, eval_measures=acc), iters)
+    win = evalops.crop_window("kitti", 375, 1242, True, False)
+    out.append(dict(case="eval_errors kitti B=%d (garg window %dx%d)" % (B, win[1] - win[0], win[3] - win[2]), sec=t,
+                    alg_gbs=B * (win[1] - win[0]) * (win[3] - win[2]) * 8 / t / 1e9))
+    big = torch.rand(32, 1, 704, 1216, device=DEV) * 80
+    t = timeit(lambda: evalops.depth_to_uint16(big, "kitti"), iters)
+    out.append(dict(case="depth_to_uint16 B=32 704x1216", sec=t, alg_gbs=big.numel() * 6 / t / 1e9))
     return out
 
 

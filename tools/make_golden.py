@@ -180,6 +180,27 @@ def gen_model_c1(ref):
     save("model_c1_densenet121", **arr)
 
 
+def gen_eval():
+    """compute_errors (bts_main.py:143-165): bts_main cannot be imported here (tensorboardX / cv2 missing), so the
+    function's own source text is executed from the unmodified file.  Inputs: masked pixel lists as online_eval()
+    builds them (oracle.eval_oracle.eval_prepare) for a kitti kb-crop + garg-crop case and a nyu eigen-crop case."""
+    from oracle import eval_oracle as E
+    src = open(os.path.join(ref_loader.REF_ROOT, "pytorch", "bts_main.py")).read().splitlines()
+    start = next(i for i, l in enumerate(src) if l.startswith("def compute_errors("))
+    end = next(i for i in range(start + 1, len(src)) if src[i].startswith("def "))
+    ns = {"np": np}
+    exec("\n".join(src[start:end]), ns)
+    ref_fn = ns["compute_errors"]
+    out = {}
+    for tag, (gh, gw, ph, pw, md, kb, garg, eig, ds) in E.EVAL_CASES.items():
+        pred, gt = E.synth_eval_case(tag)
+        pf, valid = E.eval_prepare(pred, gt, 1e-3, md, ds, kb, garg, eig)
+        out[tag + "_measures"] = np.array(ref_fn(gt[valid], pf[valid]), dtype=np.float64)
+        out[tag + "_nvalid"] = np.array(int(valid.sum()))
+        out[tag + "_checksum"] = np.array([float(pred[np.isfinite(pred)].astype(np.float64).sum()), float(gt.astype(np.float64).sum())])
+    save("eval", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_loader.load_reference()
@@ -189,7 +210,12 @@ def main():
     gen_decoder_small(ref)
     gen_decoder_dn161(ref)
     gen_model_c1(ref)
+    gen_eval()
 
+
+if __name__ == "__main__" and "--eval-only" in sys.argv:
+    gen_eval()
+    sys.exit(0)
 
 if __name__ == "__main__":
     main()
