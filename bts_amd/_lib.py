@@ -49,6 +49,11 @@ class PackJob(C.Structure):
                 ("tapmask", C.c_uint16 * MAX_TAP), ("first_block", C.c_int32)]
 
 
+class AugParams(C.Structure):
+    _fields_ = [("crop_x", C.c_int32), ("crop_y", C.c_int32), ("flip", C.c_int32), ("augment", C.c_int32),
+                ("gamma", C.c_float), ("brightness", C.c_float), ("color", C.c_double * 3)]
+
+
 class UnpackJob(C.Structure):
     _fields_ = [("dwp_off", C.c_int64), ("gw_off", C.c_int64), ("kinv", C.c_void_p),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("KK", C.c_int32), ("K", C.c_int32), ("T", C.c_int32),
@@ -72,6 +77,7 @@ SIGNATURES = {
     "bts_eval_workspace_bytes": [_i],
     "bts_eval_errors": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _i, _i, _p, _p, _p, _p],
     "bts_depth_to_u16": [_p, _p, _l, _f, _p],
+    "bts_preprocess_train": [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p],
     "bts_silog_workspace_bytes": [_l],
     "bts_silog_fwd": [_p, _p, _p, _f, _l, _f, _p, _p, _p, _p],
     "bts_silog_bwd": [_p, _p, _p, _f, _l, _f, _p, _p, _p, _p, _p],

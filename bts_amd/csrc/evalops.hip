@@ -151,3 +151,51 @@ extern "C" int bts_depth_to_u16(const float* depth, uint16_t* out, long n, float
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }
+
+// ---- training-sample preprocessing on the device ------------------------------------
+// bts_dataloader.py:126-136 (uint8 -> f32 / 255, depth payload -> metres), :190-199 (random crop), :201-213 (flip),
+// :215-235 (gamma / brightness / colour augmentation + clip), :240-250 (ToTensor + ImageNet normalise), fused: one read
+// of the decoded uint8 image and raw depth, one write of the model inputs.  The random draws stay on the host
+// (bts_aug_t, one per sample) so the data order and augmentation statistics are the reference's.
+namespace {
+
+__global__ __launch_bounds__(256) void preprocess_train_kernel(const uint8_t* __restrict__ img, const int32_t* __restrict__ depth,
+                                                               const bts_aug_t* __restrict__ params, int Hs, int Ws, int H, int W,
+                                                               float depth_div, float* __restrict__ img_out, float* __restrict__ depth_out) {
+    const int b = blockIdx.y;
+    const bts_aug_t p = params[b];
+    const long npx = (long)H * W;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};     // bts_dataloader.py:243
+    for (long i = blockIdx.x * 256l + threadIdx.x; i < npx; i += (long)gridDim.x * 256) {
+        const int y = (int)(i / W), x = (int)(i % W);
+        const int sx = p.crop_x + (p.flip ? W - 1 - x : x), sy = p.crop_y + y;              // crop, then [:, ::-1]
+        const size_t s = ((size_t)b * Hs + sy) * Ws + sx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = __fdiv_rn((float)img[s * 3 + c], 255.0f);                              // :126
+            if (p.augment) {
+                v = powf(v, p.gamma);                                                        // :218  image ** gamma (f32)
+                v = __fmul_rn(v, p.brightness);                                              // :225
+                v = (float)((double)v * p.color[c]);                                         // :229-231  f32 *= f64 image
+                v = fminf(fmaxf(v, 0.f), 1.f);                                               // :232
+            }
+            img_out[((size_t)b * 3 + c) * npx + i] = __fdiv_rn(__fsub_rn(v, mean[c]), stdv[c]);   // Normalize
+        }
+        depth_out[(size_t)b * npx + i] = __fdiv_rn((float)depth[s], depth_div);              // :127-133
+    }
+}
+
+}  // namespace
+
+extern "C" int bts_preprocess_train(const uint8_t* images, const int32_t* depth_raw, const bts_aug_t* params, int batch,
+                                    int src_h, int src_w, int height, int width, float depth_div, float* image_out,
+                                    float* depth_out, bts_stream_t stream) {
+    BTS_CHECK_ARG(images && depth_raw && params && image_out && depth_out && batch > 0);
+    BTS_CHECK_ARG(height > 0 && width > 0 && src_h >= height && src_w >= width && depth_div > 0.f);
+    long blocks = ((long)height * width + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(preprocess_train_kernel, dim3((unsigned)blocks, batch), dim3(256), 0, (hipStream_t)stream, images, depth_raw,
+                       params, src_h, src_w, height, width, depth_div, image_out, depth_out);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}

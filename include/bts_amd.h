@@ -294,6 +294,24 @@ int bts_eval_errors(const float* pred, const float* gt, const uint8_t* has_valid
  * (nyu); saturates at 0 / 65535 (numpy leaves out-of-range casts undefined), nan -> 0. */
 int bts_depth_to_u16(const float* depth, uint16_t* out, long n, float scale, bts_stream_t stream);
 
+/* Training-sample preprocessing: what DataLoadPreprocess does between the decoded image
+ * and the model input, for a whole batch in one pass -- uint8 RGB -> f32 / 255 and depth payload / depth_div
+ * (pytorch/bts_dataloader.py:126-133), random crop (:190-199), horizontal flip (:201-206), gamma / brightness /
+ * colour augmentation + clip (:215-235), ToTensor + ImageNet Normalize (:240-250).  The random draws are made on the
+ * host in the reference's order (one bts_aug_t per sample, DEVICE array) so sampling statistics are unchanged.
+ *   images     [batch][src_h][src_w][3] uint8 RGB (after kb-crop / rotation, which stay on the host)
+ *   depth_raw  [batch][src_h][src_w] int32 PNG payload (metres * 256 kitti, * 1000 nyu); depth_div = 256 or 1000
+ *   image_out  [batch][3][height][width] f32 normalised;  depth_out [batch][1][height][width] f32 metres
+ * crop_x + width <= src_w and crop_y + height <= src_h are the caller's contract (random.randint bounds, :195-196). */
+typedef struct {
+    int32_t crop_x, crop_y, flip, augment;
+    float gamma, brightness;
+    double color[3];               /* np.random.uniform(0.9, 1.1, size=3): float64, applied in f64 (:228-231) */
+} bts_aug_t;
+int bts_preprocess_train(const uint8_t* images, const int32_t* depth_raw, const bts_aug_t* params, int batch,
+                         int src_h, int src_w, int height, int width, float depth_div, float* image_out,
+                         float* depth_out, bts_stream_t stream);
+
 /* Fused multi-tensor AdamW step (torch.optim.AdamW semantics, bts_main.py:371-373, 456-460) over a
  * flat list of f32 tensors: the pointer arrays and `sizes` live on the DEVICE.  bias_c1/2 = 1 - beta^t.
  * If dev_hyper != NULL, {lr, bias_c1, bias_c2} are read from dev_hyper[0..2] on the device instead of the

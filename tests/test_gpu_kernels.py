@@ -389,3 +389,36 @@ def test_depth_to_uint16_bit_exact():
         assert out.dtype == np.uint16 and np.array_equal(out, E.depth_to_uint16(d, ds))
     edge = torch.tensor([float("nan"), -1.0, 1e9, float("inf")], device=DEV)
     assert evalops.depth_to_uint16(edge, "kitti").cpu().tolist() == [0, 0, 65535, 65535]
+
+
+def test_preprocess_train_vs_reference_golden(golden_dir):
+    """bts_preprocess_train (crop + flip + gamma / brightness / colour + clip + ToTensor + Normalize in one kernel) on the
+    16 golden cases as two batches, against the oracle that is bit-identical to the reference's methods.  Samples without
+    augmentation must be bit-exact; with augmentation powf may differ from numpy's by an ulp: 2e-6 absolute on the
+    normalised image.  Depth is always bit-exact."""
+    import random
+
+    import numpy as np
+    from bts_amd import dataops
+    from oracle import data_oracle as D
+    g = np.load("%s/preprocess.npz" % golden_dir)
+    img, dep = g["image_u8"], g["depth_raw"]
+    for ds in ("kitti", "nyu"):
+        params, want = [], []
+        for seed in range(1, 9):
+            p = D.draw_train_params(seed, 48, 80, 32, 64, ds)
+            want.append((p, D.preprocess_train(img, dep, p, 32, 64, ds)))
+            random.seed(seed)
+            np.random.seed(seed)
+            params.append(dataops.draw_train_params(48, 80, 32, 64, ds))
+        I = torch.tensor(np.stack([img] * 8)).to(DEV)
+        Z = torch.tensor(np.stack([dep] * 8)).to(DEV)
+        out_i, out_d = dataops.preprocess_train(I, Z, params, 32, 64, ds)
+        assert out_i.shape == (8, 3, 32, 64) and out_d.shape == (8, 1, 32, 64)
+        for b, (p, (chw, d, _)) in enumerate(want):
+            assert np.array_equal(out_d[b].cpu().numpy(), d), (ds, b)
+            got = out_i[b].cpu().numpy()
+            if p["augment"]:
+                assert np.abs(got - chw).max() <= 2e-6, (ds, b, np.abs(got - chw).max())
+            else:
+                assert np.array_equal(got, chw), (ds, b)

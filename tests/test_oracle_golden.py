@@ -178,3 +178,32 @@ def test_eval_oracle_uint16_payload():
     d = np.array([[0.0, 0.0039, 1.0, 79.999, 80.0]], dtype=np.float32)
     assert E.depth_to_uint16(d, "kitti").tolist() == [[0, 0, 256, 20479, 20480]]
     assert E.depth_to_uint16(d[:, :3], "nyu").tolist() == [[0, 3, 1000]]
+
+
+def test_preprocess_oracle_matches_reference_methods(golden_dir):
+    """oracle/data_oracle.py vs random_crop / train_preprocess / augment_image executed from the unmodified
+    bts_dataloader.py (tests/golden/preprocess.npz): bit-identical on 16 seeded cases covering flip x augment x dataset;
+    and bts_amd.dataops.draw_train_params consumes the generators in the same order."""
+    import random
+
+    import numpy as np
+    from bts_amd import dataops
+    from oracle import data_oracle as D
+    g = np.load("%s/preprocess.npz" % golden_dir)
+    img, dep = g["image_u8"], g["depth_raw"]
+    seen = set()
+    for ds in ("kitti", "nyu"):
+        for seed in range(1, 9):
+            p = D.draw_train_params(seed, 48, 80, 32, 64, ds)
+            chw, d, hwc = D.preprocess_train(img, dep, p, 32, 64, ds)
+            assert np.array_equal(hwc, g["%s_%d_image" % (ds, seed)]), (ds, seed)
+            assert np.array_equal(d.transpose(1, 2, 0), g["%s_%d_depth" % (ds, seed)]), (ds, seed)
+            assert chw.shape == (3, 32, 64) and chw.dtype == np.float32
+            seen.add((p["flip"], p["augment"]))
+            random.seed(seed)
+            np.random.seed(seed)
+            q = dataops.draw_train_params(48, 80, 32, 64, ds)
+            assert (q.crop_x, q.crop_y, q.flip, q.augment) == (p["crop_x"], p["crop_y"], p["flip"], p["augment"])
+            assert q.gamma == np.float32(p["gamma"]) and q.brightness == np.float32(p["brightness"])
+            assert list(q.color) == [float(c) for c in p["colors"]]
+    assert seen == {(0, 0), (0, 1), (1, 0), (1, 1)}

@@ -130,6 +130,17 @@ def misc_cases(B, H, W, iters):
     big = torch.rand(32, 1, 704, 1216, device=DEV) * 80
     t = timeit(lambda: evalops.depth_to_uint16(big, "kitti"), iters)
     out.append(dict(case="depth_to_uint16 B=32 704x1216", sec=t, alg_gbs=big.numel() * 6 / t / 1e9))
+    # training-sample preprocessing: kitti kb-cropped 352x1216 sources, batch 8, all samples augmented
+    from bts_amd import dataops
+    src = torch.randint(0, 256, (B, 352, 1216, 3), dtype=torch.uint8, device=DEV)
+    draw = torch.randint(0, 20000, (B, 352, 1216), dtype=torch.int32, device=DEV)
+    ps = []
+    for _ in range(B):
+        p = dataops.draw_train_params(352, 1216, 352, 1216, "kitti")
+        p.augment, p.gamma, p.brightness = 1, 1.05, 0.95
+        ps.append(p)
+    t = timeit(lambda: dataops.preprocess_train(src, draw, ps, 352, 1216, "kitti"), iters)
+    out.append(dict(case="preprocess_train kitti B=%d 352x1216 (augmented)" % B, sec=t, alg_gbs=B * 352 * 1216 * (3 + 4 + 12 + 4) / t / 1e9))
     return out
 
 

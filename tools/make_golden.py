@@ -201,6 +201,46 @@ def gen_eval():
     save("eval", **out)
 
 
+def gen_preprocess():
+    """random_crop / train_preprocess / augment_image executed from the source of the unmodified bts_dataloader.py
+    (methods of DataLoadPreprocess; the module needs torchvision, so the three method bodies are exec'd into a stub
+    class).  Small synthetic decoded images; seeds chosen to cover flip / no flip and augment / no augment."""
+    import random as pyrandom
+    import textwrap
+    src = open(os.path.join(ref_loader.REF_ROOT, "pytorch", "bts_dataloader.py")).read().splitlines()
+
+    def method(name):
+        start = next(i for i, l in enumerate(src) if l.startswith("    def %s(" % name))
+        end = next(i for i in range(start + 1, len(src)) if src[i].startswith("    def ") or src[i].startswith("class "))
+        return textwrap.dedent("\n".join(src[start:end]))
+    ns = {"np": np, "random": pyrandom}
+    body = "\n".join(textwrap.indent(method(m), "    ") for m in ("random_crop", "train_preprocess", "augment_image"))
+    exec("class Ref:\n" + body, ns)
+    out = {}
+    cases = []
+    for ds in ("kitti", "nyu"):
+        for seed in range(1, 9):
+            cases.append((ds, seed))
+    rs = np.random.RandomState(11)
+    img = rs.randint(0, 256, size=(48, 80, 3)).astype(np.uint8)
+    dep = rs.randint(0, 20000, size=(48, 80)).astype(np.int32)
+    out["image_u8"], out["depth_raw"] = img, dep
+    flips, augs = set(), set()
+    for ds, seed in cases:
+        r = ns["Ref"]()
+        r.args = NS(dataset=ds)
+        pyrandom.seed(seed)
+        np.random.seed(seed)
+        image = np.asarray(img, dtype=np.float32) / 255.0                     # bts_dataloader.py:126-133
+        depth = np.expand_dims(np.asarray(dep, dtype=np.float32), axis=2)
+        depth = depth / 1000.0 if ds == "nyu" else depth / 256.0
+        image, depth = r.random_crop(image, depth, 32, 64)
+        image, depth = r.train_preprocess(image, depth)
+        out["%s_%d_image" % (ds, seed)] = np.ascontiguousarray(image, dtype=np.float32)
+        out["%s_%d_depth" % (ds, seed)] = np.ascontiguousarray(depth, dtype=np.float32)
+    save("preprocess", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_loader.load_reference()
@@ -211,10 +251,12 @@ def main():
     gen_decoder_dn161(ref)
     gen_model_c1(ref)
     gen_eval()
+    gen_preprocess()
 
 
 if __name__ == "__main__" and "--eval-only" in sys.argv:
     gen_eval()
+    gen_preprocess()
     sys.exit(0)
 
 if __name__ == "__main__":
