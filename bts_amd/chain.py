@@ -1,6 +1,6 @@
-"""Host side of the fused inference LPG head (csrc/lpg_chain.hip): packs the 1x1-conv weights of a
-``reduction_1x1`` chain (pytorch/bts.py:83-108) into MFMA A-fragment order and launches
-``bts_lpg_chain_fwd``.
+"""Host side of the fused LPG head kernels (csrc/lpg_chain.hip): packs the 1x1-conv weights of a
+``reduction_1x1`` chain (pytorch/bts.py:83-108) into MFMA A-fragment order (and W^T fragments for the recompute
+backward) and launches ``bts_lpg_chain_fwd`` / ``bts_lpg_chain_bwd``.
 
 Fragment order: for layer l, output-row tile tm (32 rows) and K step s, one 1 KiB block = 64 lanes x 16 B where
 lane = (row & 31) + 32 * g.  bf16: 8 K values per lane; layer 0 uses the natural order k = 16 s + 8 g + e (its

@@ -1,5 +1,5 @@
-// Fused LPG head for inference: reduction_1x1 chain -> plane parameters -> normalise -> local planar
-// guidance, ONE pass over the dense feature map (pytorch/bts.py:83-122, 222-229, 124-146).
+// Fused LPG head (forward here; the recompute backward used in training is further down): reduction_1x1 chain ->
+// plane parameters -> normalise -> local planar guidance, ONE pass over the dense feature map (pytorch/bts.py:83-122, 222-229, 124-146).
 //
 //   x [cells][C0]  --1x1+ELU-->  ...  --1x1+ELU-->  [8]  --1x1-->  3 raw plane params (or 1 + sigmoid for reduc1x1)
 //   --> (sigmoid, sin/cos, L2-normalise) --> depth[k x k patch] = n4 / (n1 u + n2 v + n3) / max_depth

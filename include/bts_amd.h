@@ -86,7 +86,8 @@ int bts_lpg_head_bwd(const float* raw, int raw_stride, const float* grad_depth,
                      void* grad_raw, int grad_dtype, int grad_stride, int grad_pad,
                      int batch, int in_h, int in_w, int upratio, float max_depth, bts_stream_t stream);
 
-/* Fused inference LPG head: the whole reduction_1x1 chain (1x1 conv + ELU, halving the channels down to 8,
+/* Fused LPG head, forward (no-grad passes; in training together with bts_lpg_chain_bwd below, which recomputes it):
+ * the whole reduction_1x1 chain (1x1 conv + ELU, halving the channels down to 8,
  * bts.py:83-108) + plane parameters + normalisation + LPG + /max_depth in ONE pass over the dense feature map
  * (x is read once, depth written once; activations stay in registers, weights in LDS).
  *   x        NHWC [cells][x_stride] in `dtype`, c0 input channels
