@@ -1078,21 +1078,17 @@ __global__ __launch_bounds__(384, 3) void conv_wgrad_halo(const ConvK a) {
         const int tx = tile % tiles_x, r1 = tile / tiles_x;
         y0 = (r1 % tiles_y) * TH; n = r1 / tiles_y; x0 = tx * TW;
     };
-    // per-item constants, packed: vector << 16 | patch row << 8 | patch column (-1: none).  Consecutive lanes hold
-    // consecutive pixels, so each ds_write_b16 of the scatter covers consecutive bytes of one channel row.
-    int it[NIT], zt[NZT];
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) {
+    // item j of this thread = (channel vector, patch pixel) tid + NTHR * j, pixel-fastest: consecutive lanes hold
+    // consecutive pixels, so each ds_write_b16 of the scatter covers consecutive bytes of one channel row.  The
+    // coordinates are recomputed where needed (constant divisors) instead of being kept in registers.
+    auto patch_item = [&](int j, int& c, int& py, int& pc) {
         const int i = tid + NTHR * j;
-        const int c = i / NPIX, pix = i - c * NPIX;
-        const int py = pix / PW, pc = pix - py * PW;
-        it[j] = i < NPIX * KVG ? (c << 16 | py << 8 | pc) : -1;
-    }
-#pragma unroll
-    for (int j = 0; j < NZT; ++j) {
-        const int i = tid + NTHR * j;
-        zt[j] = i < TH * TW * 4 ? ((i >> 8) << 16 | (i & 255)) : -1;      // vector << 16 | pixel (row * 32 + x)
-    }
+        c = i / NPIX;
+        const int pix = i - c * NPIX;
+        py = pix / PW;
+        pc = pix - py * PW;
+        return i < NPIX * KVG;
+    };
     const int co_vecs = (a.Cout + 7) >> 3;
     u32x4_t xr[NIT], zr[NZT];
     auto load_tile = [&](int tile) {
@@ -1101,8 +1097,8 @@ __global__ __launch_bounds__(384, 3) void conv_wgrad_halo(const ConvK a) {
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
             u32x4_t v = {0, 0, 0, 0};
-            if (it[j] >= 0) {
-                const int c = it[j] >> 16, py = (it[j] >> 8) & 255, pc = it[j] & 255;
+            int c, py, pc;
+            if (patch_item(j, c, py, pc)) {
                 const char* base = c_base[c];
                 const int iy = y0 - 1 + py, ix = x0 - 1 + pc;
                 if (base && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx)
@@ -1113,9 +1109,9 @@ __global__ __launch_bounds__(384, 3) void conv_wgrad_halo(const ConvK a) {
 #pragma unroll
         for (int j = 0; j < NZT; ++j) {
             u32x4_t v = {0, 0, 0, 0};
-            const int zc = zt[j] >> 16, zp = zt[j] & 255;
+            const int zi = tid + NTHR * j, zc = zi >> 8, zp = zi & 255;      // dz item: vector zc of tile pixel zp
             const int oy = y0 + (zp >> 5), ox = x0 + (zp & 31);
-            if (zt[j] >= 0 && oy < a.Hg && ox < a.Wg && cog * 4 + zc < co_vecs)
+            if (zi < TH * TW * 4 && oy < a.Hg && ox < a.Wg && cog * 4 + zc < co_vecs)
                 v = *(const u32x4_t*)(a.dz + ((size_t)(n * a.Hy + oy) * a.Wy + ox) * a.dz_stride * 2 + cog * 64 + zc * 16);
             zr[j] = v;
         }
@@ -1131,13 +1127,13 @@ __global__ __launch_bounds__(384, 3) void conv_wgrad_halo(const ConvK a) {
     auto scatter_tile = [&]() {
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
-            const int c = it[j] >> 16, py = (it[j] >> 8) & 255, pc = it[j] & 255;
-            if (it[j] >= 0) scatter8(XT + c * 8 * XS + py * PROW + pc * 2, XS, xr[j]);
+            int c, py, pc;
+            if (patch_item(j, c, py, pc)) scatter8(XT + c * 8 * XS + py * PROW + pc * 2, XS, xr[j]);
         }
 #pragma unroll
         for (int j = 0; j < NZT; ++j) {
-            const int zc = zt[j] >> 16, zp = zt[j] & 255;
-            if (zt[j] >= 0) scatter8(DT + zc * 8 * DS + (zp >> 5) * 64 + (zp & 31) * 2, DS, zr[j]);
+            const int zi = tid + NTHR * j, zc = zi >> 8, zp = zi & 255;
+            if (zi < TH * TW * 4) scatter8(DT + zc * 8 * DS + (zp >> 5) * 64 + (zp & 31) * 2, DS, zr[j]);
         }
     };
     // wave role: one tap row dy (all three dx) of one 32-channel ci tile; with TN = 1 two waves split the pixel rows
