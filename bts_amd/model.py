@@ -14,8 +14,6 @@ below are parameter containers (they keep ``isinstance`` based code such as
 There is no CPU execution path: calling ``forward`` without the library or without a HIP
 device raises.
 """
-import math
-from collections import OrderedDict
 
 import torch
 import torch.nn as nn

@@ -16,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bts_amd import ops  # noqa: E402
-from bts_amd._lib import ACT_ELU, ACT_NONE, ACT_RELU  # noqa: E402
+from bts_amd._lib import ACT_ELU, ACT_RELU  # noqa: E402
 from bts_amd.conv import ConvLayer  # noqa: E402
 
 DEV = "cuda"
