@@ -78,3 +78,26 @@ def test_missing_gpu_fails_loudly():
     from bts_amd import _lib
     with pytest.raises(_lib.BtsAmdError):
         _lib.require_gpu(torch.zeros(1))
+
+
+def test_header_is_plain_c99_and_struct_layouts_match(tmp_path):
+    """include/bts_amd.h must be consumable by a C compiler (the reference-side binding is C / C++ / FFI), and the
+    ctypes mirrors of its structs must have the C layout (sizes and a few offsets printed by a tiny C program)."""
+    import shutil
+    import subprocess
+    from bts_amd import _lib
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bts_amd.h"\n'
+                   'int main(void) {\n'
+                   '  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(bts_conv_desc_t), sizeof(bts_pack_job_t), sizeof(bts_unpack_job_t),\n'
+                   '         sizeof(bts_aug_t), offsetof(bts_pack_job_t, first_block), offsetof(bts_unpack_job_t, first_block),\n'
+                   '         offsetof(bts_aug_t, color));\n  return 0;\n}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call([cc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(_lib.ConvDesc), ctypes.sizeof(_lib.PackJob), ctypes.sizeof(_lib.UnpackJob), ctypes.sizeof(_lib.AugParams),
+            _lib.PackJob.first_block.offset, _lib.UnpackJob.first_block.offset, _lib.AugParams.color.offset]
+    assert got == want, (got, want)
