@@ -1749,6 +1749,9 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
         //      8-wave workgroup, and the mid-size layers get 2x the workgroups (209 -> 418 tiles on 256 CUs).
         //   d  128co x 256px, 8 waves, 2 stages ( 96 KiB, 1 WG/CU = 2 waves/SIMD)  [early r1, before those changes: 594-644 TF
         //      on conv5/daspp_conv vs 553-592 for a]
+        //   e  256co x 256px, 8 waves, 2 stages (128 KiB, 1 WG/CU) for Cout >= 256, else a: 64 MAC per staged byte instead
+        //      of 32 -- the ISA of a (16 MFMA = 512 cycles per 32 KiB chunk) needs ~39 TB/s of L2->LDS fill at full MFMA
+        //      rate, so the tile shape, not the schedule, caps it.  A/B only (BTS_CONV_BIG=e).
         //   b  128co x 128px, 4 waves, 3 stages ( 96 KiB, 1 WG/CU = 1 wave/SIMD)   [r1: 339-368 TF: too few waves]
         //   c  128co x 256px, 8 waves, 3 stages (144 KiB)                           [r1: = d; depth is not the limiter]
         //   64co x 128px and 32co x 256px, 4 waves, 2 stages for narrow layers
@@ -1757,6 +1760,8 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
             if (big == 'b') go2(conv_igemm_dma<T, 2, 2, 2, 2, 3>, 128, 128, 256);
             else if (big == 'c') go2(conv_igemm_dma<T, 2, 4, 2, 2, 3>, 128, 256, 512);
             else if (big == 'd') go2(conv_igemm_dma<T, 2, 4, 2, 2, 2>, 128, 256, 512);
+            else if (big == 'e' && k.Cout >= 256) go2(conv_igemm_dma<T, 2, 4, 4, 2, 2>, 256, 256, 512);   // experimental, see DESIGN §10
+            else if (big == 'e') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2>, 128, 128, 256);
             else go2(conv_igemm_dma<T, 2, 2, 2, 2, 2>, 128, 128, 256);
         }
         else if (k.Cout > 32) go2(conv_igemm_dma<T, 1, 4, 2, 1, 2>, 64, 128, 256);
