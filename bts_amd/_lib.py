@@ -98,6 +98,7 @@ SIGNATURES = {
     "bts_act_bwd": [_p, _i, _i, _p, _i, _i, _p, _i, _i, _l, _i, _i, _f, _p, _l, _p],
     "bts_add_to": [_p, _i, _i, _p, _i, _i, _l, _i, _i, _p],
     "bts_adamw_step": [_p, _p, _p, _p, _p, _i, _l, _f, _f, _f, _f, _f, _f, _f, _p, _p],
+    "bts_adamw_advance": [_p, _i, _p],
 }
 _LONG_RET = {"bts_silog_workspace_bytes", "bts_bn_stats_workspace_bytes", "bts_eval_workspace_bytes"}
 _NO_CHECK = _LONG_RET | {"bts_abi_version", "bts_current_device"}

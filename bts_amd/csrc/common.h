@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/bts_amd.h"
 
 #define BTS_WAVE 64
@@ -103,3 +105,20 @@ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
         hipError_t e__ = hipGetLastError();                      \
         if (e__ != hipSuccess) return BTS_ERR_LAUNCH;            \
     } while (0)
+
+// Dynamic-LDS opt-in of a kernel (needed above 48 KiB), remembered per device so it is a host call only the first
+// time a (kernel, device) pair needs more than it already has.  The cache is idempotent (racing threads set the same
+// attribute) and is not a stream operation, so it never lands inside a graph capture after the warm-up pass.
+struct DynLdsCache {
+    std::atomic<int> set[32];
+};
+static inline int ensure_dyn_lds(const void* kern, int bytes, DynLdsCache& c) {
+    if (bytes <= 48 * 1024) return BTS_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return BTS_ERR_LAUNCH;
+    if (bytes > c.set[dev].load(std::memory_order_relaxed)) {
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return BTS_ERR_LAUNCH;
+        c.set[dev].store(bytes, std::memory_order_relaxed);
+    }
+    return BTS_OK;
+}

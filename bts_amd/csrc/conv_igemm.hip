@@ -1832,12 +1832,8 @@ static int launch_wgrad(const ConvK& k0, hipStream_t st) {
             if (workers > ntiles) workers = ntiles;
             const int lds = 32 * tn * (10 * 80 + 16) + 4 * 32 * (8 * 64 + 16);
             auto kern = tn == 2 ? conv_wgrad_halo_up<2> : conv_wgrad_halo_up<1>;
-            static int lds_set[3] = {0, 0, 0};
-            if (!lds_set[tn]) {
-                if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-                    return BTS_ERR_LAUNCH;
-                lds_set[tn] = 1;
-            }
+            static DynLdsCache lds_set[3];
+            if (ensure_dyn_lds((const void*)kern, lds, lds_set[tn]) != BTS_OK) return BTS_ERR_LAUNCH;
             hipLaunchKernelGGL(kern, dim3(workers, cigs, cogs), dim3(512), (size_t)lds, st, k);
             BTS_LAUNCH_CHECK();
             return BTS_OK;
@@ -1853,12 +1849,8 @@ static int launch_wgrad(const ConvK& k0, hipStream_t st) {
             if (workers > ntiles) workers = ntiles;
             const int lds = 32 * tn * (10 * 80 + 16) + 32 * (8 * 64 + 16);
             auto kern = tn == 2 ? conv_wgrad_halo<2> : conv_wgrad_halo<1>;
-            static int lds_set[3] = {0, 0, 0};
-            if (lds > 48 * 1024 && !lds_set[tn]) {
-                if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-                    return BTS_ERR_LAUNCH;
-                lds_set[tn] = 1;
-            }
+            static DynLdsCache lds_set[3];
+            if (ensure_dyn_lds((const void*)kern, lds, lds_set[tn]) != BTS_OK) return BTS_ERR_LAUNCH;
             hipLaunchKernelGGL(kern, dim3(workers, cigs, cogs), dim3(384), (size_t)lds, st, k);
             BTS_LAUNCH_CHECK();
             return BTS_OK;

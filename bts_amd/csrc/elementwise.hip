@@ -389,6 +389,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ p
     }
 }
 
+// one thread per parameter group: row = {lr, bc1, bc2, step, beta1, beta2, -, -}
+__global__ void adamw_advance_kernel(float* __restrict__ rows, int n_groups) {
+    const int g = threadIdx.x;
+    if (g >= n_groups) return;
+    float* h = rows + 8 * g;
+    const float step = h[3] + 1.f;
+    h[3] = step;
+    h[1] = (float)(1.0 - pow((double)h[4], (double)step));
+    h[2] = (float)(1.0 - pow((double)h[5], (double)step));
+}
+
 #define DISPATCH_T(dt, FN, ...)                       \
     do {                                              \
         if ((dt) == BTS_F32) { FN(F32, __VA_ARGS__); } \
@@ -594,6 +605,13 @@ extern "C" int bts_adamw_step(float* const* params, float* const* grads, float* 
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, params, grads,
                        exp_avg, exp_avg_sq, sizes, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2, dev_hyper);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_adamw_advance(float* dev_hyper_rows, int n_groups, bts_stream_t stream) {
+    BTS_CHECK_ARG(dev_hyper_rows && n_groups > 0 && n_groups <= 64);
+    hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_hyper_rows, n_groups);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }

@@ -243,10 +243,8 @@ __global__ __launch_bounds__(256) void lpg_chain_fwd_kernel(const ChainK a) {
 template <typename T, int C0, bool SAME, int KUP>
 int launch_chain(const ChainK& k, hipStream_t st) {
     auto kern = lpg_chain_fwd_kernel<T, C0, SAME, KUP>;
-    if (k.w_bytes > 48 * 1024) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, k.w_bytes) != hipSuccess)
-            return BTS_ERR_LAUNCH;
-    }
+    static DynLdsCache lds_set;        // per instantiation
+    if (ensure_dyn_lds((const void*)kern, k.w_bytes, lds_set) != BTS_OK) return BTS_ERR_LAUNCH;
     const long ntiles = (k.cells + 31) / 32;
     long blocks = (ntiles + 3) / 4;
     // resident workgroups per CU allowed by LDS (weights) and registers; grid-stride beyond that
@@ -560,12 +558,8 @@ int launch_chain_bwd(const ChainBwdK& k, hipStream_t st) {
     auto kern = lpg_chain_bwd_kernel<C0, KUP>;
     const int lds = k.wf_bytes + k.wt_bytes + SCR_BYTES;
     if (lds > 160 * 1024) return BTS_ERR_UNSUPPORTED;
-    static int lds_set = 0;      // per instantiation; not a stream operation, so done once outside any graph capture window
-    if (lds > 48 * 1024 && lds > lds_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return BTS_ERR_LAUNCH;
-        lds_set = lds;
-    }
+    static DynLdsCache lds_set;  // per instantiation; not a stream operation, so done once outside any graph capture window
+    if (ensure_dyn_lds((const void*)kern, lds, lds_set) != BTS_OK) return BTS_ERR_LAUNCH;
     const long ntiles = (k.cells + 31) / 32;
     long blocks = (ntiles + 3) / 4;
     int per_cu = C0 >= 64 ? 2 : 4;                   // resident workgroups per CU allowed by registers ...

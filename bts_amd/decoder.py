@@ -192,10 +192,11 @@ class DecoderRun:
         self.outs = None
         names = list(plan.layers)
         key = (dtype, tuple(P[n + ".weight"].data_ptr() for n in names))
-        ps = plan.pack_cache.get(dtype)
+        dev = P[names[0] + ".weight"].device
+        ps = plan.pack_cache.get((dtype, dev))           # per device: DataParallel replicas share the plan
         if ps is None or ps.key != key:
             ps = PackSet(plan, P, dtype)
-            plan.pack_cache[dtype] = ps
+            plan.pack_cache[(dtype, dev)] = ps
         self.packs = ps
         self.dwp_arena = None
 
@@ -349,9 +350,9 @@ class DecoderRun:
         on every pass (two gathers through cached indices): nothing keyed on tensor versions, so in-place /
         graph-replayed optimizer updates are always seen."""
         cache = self.plan.chain_cache
-        key = (name, start, self.dtype)
+        key = (name, start, self.dtype, ws[0].device)
         pk = cache.get(key)
-        if pk is None or pk.idx_fwd.device != ws[0].device:
+        if pk is None:
             pk = chain_mod.ChainPacker([(w.shape[0], w.shape[1]) for w in ws], self.dtype, ws[0].device)
             cache[key] = pk
         return pk.pack(ws, with_t)

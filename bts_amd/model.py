@@ -15,6 +15,8 @@ There is no CPU execution path: calling ``forward`` without the library or witho
 device raises.
 """
 
+import operator
+
 import torch
 import torch.nn as nn
 
@@ -188,6 +190,9 @@ class _DecoderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
+        if ctx.run is None:
+            raise BtsAmdError("the bts decoder keeps one backward tape per forward pass: a second backward() through the "
+                              "same forward (retain_graph=True) is not supported -- run the forward again")
         gfeats, grads = ctx.run.backward(gouts)
         ctx.run = None
         gp = [grads.get(n) for n in ctx.names]
@@ -240,6 +245,8 @@ class bts(nn.Module):
         self.get_depth = torch.nn.Sequential(nn.Conv2d(nf // 16, 1, 3, 1, 1, bias=False), nn.Sigmoid())
 
         self._plan = DecoderPlan(f, nf)
+        self._param_names = tuple(n for n, _ in self.named_parameters())
+        self._param_getters = tuple(operator.attrgetter(n) for n in self._param_names)
         # activation dtype of the decoder kernels: f32 (parity) or bf16 (throughput); not a parameter
         self.compute_dtype = getattr(params, "decoder_dtype", torch.float32)
         if isinstance(self.compute_dtype, str):
@@ -249,7 +256,10 @@ class bts(nn.Module):
     def forward(self, features, focal):
         feats = list(features[:5])
         require_gpu(feats[0])
-        names, params = zip(*self.named_parameters())
+        # parameters by cached dotted name: nn.DataParallel replicas (bts_main.py:357, bts_test.py:90) carry them as
+        # plain tensor attributes and expose nothing through named_parameters()
+        names = self._param_names
+        params = tuple(g(self) for g in self._param_getters)
         # record the backward tape only when autograd will ask for it; the no-grad path (bts_test.py:118-119,
         # online_eval) runs the fused inference LPG heads and keeps no activations
         record = torch.is_grad_enabled() and (any(f.requires_grad for f in feats) or any(p.requires_grad for p in params))

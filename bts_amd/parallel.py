@@ -18,22 +18,30 @@ exchange step of the hot path is the mean of the gradients across ranks, once pe
   xGMI links (7 x ~153 GB/s per GPU), so per-message latency, not switch bandwidth, is what small
   buckets pay for; ~47 M parameters (DenseNet161-BTS, 188 MB f32) become 3 large messages.
 
+One synchronising backward per step (hooks count gradients down to zero); gradient accumulation uses
+``no_sync()`` for the earlier micro-batches, and a stray second backward raises instead of racing the in-flight exchange.
+
 The mean is computed as SUM followed by one in-place scale of the flat bucket (ReduceOp.AVG is not
 available on the gloo backend used by the CPU tests).
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, params, bucket_bytes=64 << 20, process_group=None):
+    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, reduce_single=False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # reduce_single: issue the collectives even at world size 1 (exercises the RCCL path on a one-GPU box)
+        self.collective = self.world > 1 or (reduce_single and dist.is_initialized())
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []        # (flat tensor, [params])
         self._pending = {}
         self._works = []
         self._hooks = []
+        self._defer = False
         self._build(bucket_bytes)
 
     def _build(self, bucket_bytes):
@@ -60,10 +68,27 @@ class GradAllReducer:
 
     def _make_hook(self, bi):
         def hook(param):
+            if self._defer:                         # inside no_sync(): gradients only accumulate in the bucket
+                return
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
                 self._launch(bi)
+            elif self._pending[bi] < 0:
+                raise RuntimeError(
+                    "GradAllReducer: a second backward() reached bucket %d after its all-reduce was launched; the "
+                    "contract is ONE synchronising backward per zero_grad()/finish() pair -- wrap the earlier "
+                    "micro-batch backwards of a gradient-accumulation step in `with reducer.no_sync():`" % bi)
         return hook
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation (the DDP idiom): backward passes inside this context only add into the flat buckets;
+        the exchange is launched by the first backward outside it (or by finish())."""
+        self._defer = True
+        try:
+            yield
+        finally:
+            self._defer = False
 
     def _reset(self):
         self._pending = {bi: len(ps) for bi, (_, ps) in enumerate(self.buckets)}
@@ -71,7 +96,7 @@ class GradAllReducer:
 
     def _launch(self, bi):
         flat = self.buckets[bi][0]
-        if self.world > 1:
+        if self.collective:
             self._works.append((bi, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     def zero_grad(self):

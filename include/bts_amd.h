@@ -5,7 +5,9 @@
  * and their wrappers local_planar_guidance.cc:182-231, 365-416):
  *   - plain C, raw device pointers + sizes; no framework types;
  *   - the CALLER allocates every output and every workspace; the library never
- *     allocates, frees, synchronises or keeps mutable global state;
+ *     allocates, frees or synchronises, and keeps no state that results depend on (the only
+ *     process-wide data are idempotent per-device caches of "this kernel's dynamic-LDS limit
+ *     was raised" and environment A/B switches read once);
  *   - every entry point enqueues on the caller's stream (`stream` is a hipStream_t
  *     passed as void*; the reference enqueues on d.stream() then blocks with
  *     d.synchronize(), local_planar_guidance.cu:88-91 -- we do not block);
@@ -321,6 +323,12 @@ int bts_adamw_step(float* const* params, float* const* grads, float* const* exp_
                    const long* sizes, int n_tensors, long max_size, float lr, float beta1, float beta2,
                    float eps, float weight_decay, float bias_c1, float bias_c2, const float* dev_hyper,
                    bts_stream_t stream);
+/* Device-side step counter of the optimizer (one 8-float row per parameter group:
+ * {lr, bias_c1, bias_c2, step, beta1, beta2, -, -}): step += 1, bias_c{1,2} = 1 - beta{1,2}^step.  Enqueued in front of
+ * bts_adamw_step (whose dev_hyper points at the group's row), it makes a captured hipGraph advance the AdamW step on
+ * every replay; the host only rewrites `lr` (per-step poly schedule, bts_main.py:456-458) and reads `step` back when a
+ * checkpoint is written (bts_main.py:498-503). */
+int bts_adamw_advance(float* dev_hyper_rows, int n_groups, bts_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,34 @@ def _worker(rank, world, port, bucket_bytes, q):
                 g /= world
                 assert torch.allclose(p.grad, g, rtol=1e-6, atol=1e-7), (n, it)
                 assert p.grad.data_ptr() >= red.buckets[0][0].data_ptr() or True
+        # gradient accumulation: two micro-batches, the first under no_sync(); mean over ranks of the SUM of both
+        x2 = torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(10 + rank))
+        red.zero_grad()
+        with red.no_sync():
+            net(x).pow(2).mean().backward()
+        net(x2).pow(2).mean().backward()
+        red.finish()
+        ref.zero_grad()
+        ref(x).pow(2).mean().backward()
+        ref(x2).pow(2).mean().backward()
+        for (n, p), (_, pr) in zip(net.named_parameters(), ref.named_parameters()):
+            if p.requires_grad:
+                g = pr.grad.clone() if pr.grad is not None else torch.zeros_like(pr)
+                dist.all_reduce(g)
+                g /= world
+                assert torch.allclose(p.grad, g, rtol=1e-5, atol=1e-7), ("accum", n)
+        # a stray second synchronising backward must raise, not race the exchange in flight
+        red.zero_grad()
+        net(x).pow(2).mean().backward()
+        try:
+            net(x2).pow(2).mean().backward()
+            raise AssertionError("second backward did not raise")
+        except RuntimeError as e:
+            assert "no_sync" in str(e)
+        red.finish()
+        red.zero_grad()
+        net(x).pow(2).mean().backward()
+        red.finish()
         # every rank ends with identical gradients (what the optimizer sees)
         flat = torch.cat([b[0] for b in red.buckets])
         gathered = [torch.zeros_like(flat) for _ in range(world)]
