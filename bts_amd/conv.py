@@ -13,6 +13,8 @@ materialises the up-sampled tensor.
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib, profiler
@@ -67,6 +69,8 @@ def _wgrad_kernel(dtype, cout, radius1, up, n, hg, wg):
         return "conv_wgrad_c1<%s>" % _dn(dtype)
     if radius1 and cout <= 64 and dtype == torch.bfloat16 and _cdiv(wg, 32) * _cdiv(hg, 8) * n >= 256:
         return "conv_wgrad_halo_up<bf16>" if up else "conv_wgrad_halo<bf16>"
+    if cout > 64 and dtype == torch.bfloat16 and os.environ.get("BTS_WGRAD_TR", "1")[:1] != "0":
+        return "conv_wgrad_tr<bf16,128x128>"
     return "conv_wgrad<%s,%s>" % (_dn(dtype), "128x128" if cout > 64 else ("64x128k2" if cout > 32 else "32x128k4"))
 
 

@@ -17,97 +17,11 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "conv_common.h"
 
 namespace {
 
-struct FastDiv {
-    uint32_t m, s;
-};
-static FastDiv make_fastdiv(uint32_t d) {
-    FastDiv f;
-    uint32_t s = 0;
-    while ((1ull << s) < d) ++s;
-    f.s = s;
-    f.m = (uint32_t)((((1ull << s) - d) << 32) / d + 1);
-    return f;
-}
-__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return (__umulhi(n, f.m) + n) >> f.s; }
-
-struct ConvK {
-    const char* seg_ptr[BTS_MAX_SEG];
-    int seg_stride[BTS_MAX_SEG];
-    int seg_cum[BTS_MAX_SEG + 1];  // in 16-byte vectors
-    int nseg, KV;                  // KV = vectors per tap
-    int N, Hg, Wg, M;
-    FastDiv fd_w, fd_hw;
-    int Hx, Wx, isc;
-    int T, nphase, Ttot;
-    uint32_t taps[BTS_MAX_TAP];  // dy:8 | dx:8 | ioy:4 | iox:4
-    int tapoff[BTS_MAX_TAP];     // input-pixel offset of the tap: (dy*isc+ioy)*Wx + dx*isc + iox
-    uint32_t seg_sb[BTS_MAX_SEG];  // pixel stride of each segment in BYTES
-    const char* w;
-    int Cout, Ktot;
-    char* y;
-    int y_stride, Hy, Wy, osc, y_f32, act, accumulate, vec_store;
-    float out_scale;
-    const float* out_scale_n;
-    int n_px_tiles, n_co_tiles;
-    // wgrad only
-    const char* dz;
-    int dz_stride;
-    float* dw;
-    int n_col_tiles, nchunks, chunks_per_split;
-    int halo_ok;   // every tap within radius 1 on an unscaled same-size input: eligible for conv_halo
-    int kmajor;    // conv_igemm_dma K order: 1 = channel chunk outer, taps inner (needs KV % 8 == 0); 0 = tap outer
-};
-
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-__device__ __forceinline__ int remap_xcd(int b, int nb) {
-    // blocks are dealt round-robin to the 8 XCDs; give each XCD a contiguous range of logical tiles
-    const int xcd = b & 7, q = nb >> 3, r = nb & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-}
-
-template <typename T>
-struct Mma;
-template <>
-struct Mma<BF16> {
-    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x16_t& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-    }
-};
-template <>
-struct Mma<F32> {
-    __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x16_t& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
-    }
-};
-
-__device__ __forceinline__ void decode_tap(uint32_t tp, int& dy, int& dx, int& ioy, int& iox) {
-    dy = (int)(int8_t)(tp & 0xff);
-    dx = (int)(int8_t)((tp >> 8) & 0xff);
-    ioy = (tp >> 16) & 0xf;
-    iox = (tp >> 20) & 0xf;
-}
-
-// select the input segment that holds channel-vector cv
-__device__ __forceinline__ void pick_seg(const ConvK& a, int cv, const char*& sp, int& sst, int& coff) {
-    sp = a.seg_ptr[0];
-    sst = a.seg_stride[0];
-    coff = cv;
-#pragma unroll
-    for (int s = 1; s < BTS_MAX_SEG; ++s) {
-        if (s < a.nseg && cv >= a.seg_cum[s]) {
-            sp = a.seg_ptr[s];
-            sst = a.seg_stride[s];
-            coff = cv - a.seg_cum[s];
-        }
-    }
-}
+using namespace bts_conv;
 
 template <typename T, int WR, int WC, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16_t (&acc)[TM][TN], int co_tile, int px_tile, int phase,
@@ -298,41 +212,6 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK a) {
     conv_epilogue<T, WR, WC, TM, TN>(a, acc, co_tile, px_tile, phase, wr, wc, frow, fk);
 }
 
-// segment lookup for the strength-reduced address path: index, base pointer, byte stride, channel byte offset
-__device__ __forceinline__ void pick_seg_b(const ConvK& a, int cv, int vec_bytes, int& seg, const char*& sp, uint32_t& sb,
-                                           uint32_t& coffB, int& seg_end) {
-    seg = 0;
-    sp = a.seg_ptr[0];
-    sb = a.seg_sb[0];
-    int coff = cv;
-    seg_end = a.nseg > 1 ? a.seg_cum[1] : a.KV;
-#pragma unroll
-    for (int s = 1; s < BTS_MAX_SEG; ++s) {
-        if (s < a.nseg && cv >= a.seg_cum[s]) {
-            seg = s;
-            sp = a.seg_ptr[s];
-            sb = a.seg_sb[s];
-            coff = cv - a.seg_cum[s];
-            seg_end = s + 1 < a.nseg ? a.seg_cum[s + 1] : a.KV;
-        }
-    }
-    coffB = (uint32_t)(coff * vec_bytes);
-}
-
-// ------------------------------------------------------------------------------------------------
-// forward / data-gradient kernel, LDS-DMA staging (global_load_lds_dwordx4, 16 B per lane)
-//
-// Same math and LDS image as conv_igemm, but tiles go HBM -> LDS directly (no staging VGPRs, no
-// ds_write pass) into a double buffer, with ONE barrier per K chunk: the DMA of chunk c+1 is in
-// flight while the MFMAs of chunk c run.  The DMA destination is lane-linear (wave-uniform base +
-// lane*16 B), so the XOR swizzle of the LDS image is applied to the per-lane SOURCE address instead
-// (lane (row, pc) fetches logical chunk pc ^ ((row>>1)&7)); padding / out-of-image taps read a
-// 64-byte zero page instead of being predicated.
-// ------------------------------------------------------------------------------------------------
-__device__ const uint32_t kZeroPage[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 // NS-stage pipeline: the DMA of chunk c+NS-1 is issued right after the barrier that retires chunk c-1's
 // buffer; a counted s_waitcnt vmcnt((NS-2)*G) (G = DMA instructions per thread per chunk) retires
@@ -1855,6 +1734,12 @@ static int launch_wgrad(const ConvK& k0, hipStream_t st) {
             BTS_LAUNCH_CHECK();
             return BTS_OK;
         }
+    }
+    // wide bf16 layers: LDS-DMA + transposing LDS reads (conv_wgrad_tr.hip); BTS_WGRAD_TR=0 keeps the register-transpose kernel (A/B)
+    static const int tr_on = [] { const char* e = getenv("BTS_WGRAD_TR"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (T::kBytes == 2 && k.Cout > 64 && tr_on) {
+        const int rc = launch_wgrad_tr(k, st);
+        if (rc != BTS_ERR_UNSUPPORTED) return rc;
     }
     if (k.Cout > 64) go(conv_wgrad<T, 2, 2, 1, 2, 2>, 128, 128);
     else if (k.Cout > 32) {

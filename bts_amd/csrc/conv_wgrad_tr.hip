@@ -1,0 +1,239 @@
+// Weight gradient of the wide decoder convolutions (bf16, Cout > 64) on CDNA4 matrix cores.
+//
+//     dW[co][tap][k] = sum_p dZ[p][co] * X[p + tap][k]            (bts.py:51-80, 153-194: autograd of every Conv2d)
+//
+// The contraction runs over PIXELS, which is the strided index of both NHWC operands, while an MFMA lane wants 8
+// consecutive K values.  conv_wgrad (conv_igemm.hip) transposes both operands in registers while staging them
+// (global -> VGPR -> v_perm 8x8 -> ds_write) and is bound by exactly that.  Here nothing is transposed by the VALU:
+//
+//   * both operands go HBM/L2 -> LDS as they lie in memory, pixel-major rows of 64 channels (128 B), by LDS-DMA
+//     (global_load_lds_dwordx4; no staging VGPRs, no ds_write pass), double-buffered with a counted vmcnt and one raw
+//     s_barrier per 64-pixel chunk exactly like conv_igemm_dma;
+//   * the MFMA fragments are read with ds_read_b64_tr_b16, gfx950's transposing LDS read: a 16-lane group reads a
+//     [4 pixels][16 channels] block (8 B per lane along the channels) and every lane receives ONE channel's 4 pixels,
+//     so two reads give the 8 K-contiguous values of a 32x32x16 fragment;
+//   * taps are row offsets of the pixel-major image (never sub-dword shifts), padding reads a zero page;
+//   * the bank mapping of the transposing read (32 lanes = 4 pixel rows x 64 B per LDS cycle) is made conflict-free by
+//     swapping the two 64-byte halves of every other pixel-row pair, applied on the DMA SOURCE side (the LDS-DMA
+//     destination is lane-linear) and undone in the read address;
+//   * one workgroup owns a 128 (co) x 128 (tap,k) tile of dW and a contiguous range of pixel chunks; the split over
+//     pixels is only as deep as it takes to fill the chip (conv5: 252 tiles, no split at all), instead of the 1024
+//     workgroups x f32 atomics of conv_wgrad that wrote 5x the size of dW.
+#include "conv_common.h"
+
+namespace bts_conv {
+namespace {
+
+
+// lane -> (pixel row, 8-byte channel group) inside the [4][16] block a 16-lane group reads (see tools/probes/tr_probe.hip)
+#ifndef BTS_TR_ROWMAP
+#define BTS_TR_ROWMAP 0
+#endif
+__device__ __forceinline__ int tr_key(int i16) { return BTS_TR_ROWMAP ? (i16 & 3) : (i16 >> 2); }
+__device__ __forceinline__ int tr_cg(int i16) { return BTS_TR_ROWMAP ? (i16 >> 2) : (i16 & 3); }
+
+// The transposing read is issued from inline asm: hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of the
+// __builtin_amdgcn_ds_read_tr16_b64 builtin whenever an LDS-DMA is in flight (it cannot see that the DMA targets the
+// OTHER stage buffer), which would serialise the whole pipeline.  The compiler therefore does not know these are memory
+// operations: every use of a result is preceded by an explicit counted s_waitcnt lgkmcnt + sched_barrier below
+// (cdna_hip_programming.md rule 18), and the generated ISA was checked for copies of the result registers ahead of
+// those waits (there are none: the two halves are coalesced into the MFMA operand tuple).
+template <int OFF>
+__device__ __forceinline__ void tr_issue(u32x2_t& d, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+struct Frag { u32x2_t lo, hi; };
+__device__ __forceinline__ u32x4_t frag_vec(const Frag& f) { return u32x4_t{f.lo.x, f.lo.y, f.hi.x, f.hi.y}; }
+template <int S>
+__device__ __forceinline__ void tr_frag(Frag& f, uint32_t addr) {          // k-step S: pixels 16*S .. 16*S+15
+    tr_issue<S * 16 * 128>(f.lo, addr);
+    tr_issue<S * 16 * 128 + 512>(f.hi, addr);                                // pixels +4
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+constexpr int KC = 64;                 // pixels per K chunk
+constexpr int SUB = KC * 128;          // one sub-tile: KC pixel rows x 64 channels (128 B)
+constexpr int STAGE = 4 * SUB;         // A0 A1 B0 B1
+constexpr int G = 8;                   // DMA instructions per thread per chunk
+
+template <int NS>
+__global__ __launch_bounds__(256) void conv_wgrad_tr(const ConvK a) {
+    static_assert((NS - 2) * G <= 63, "vmcnt range");
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int phase = blockIdx.z, split = blockIdx.y;
+    const int L = remap_xcd(blockIdx.x, a.n_co_tiles * a.n_col_tiles);
+    const int co_tile = L % a.n_co_tiles, col_tile = L / a.n_co_tiles;
+    const int pa = phase >> 1, pb = phase & 1;
+    const char* zero = (const char*)kZeroPage;
+
+    // ---- DMA roles: physical piece pc of pixel row r0 (+32) of each of the four sub-tiles ------------------------------
+    const int pc = tid & 7, r0 = tid >> 3;
+    const int lp = pc ^ (((r0 >> 1) & 1) << 2);                 // logical 16-byte piece this lane must fetch (half swap)
+    const char* abase[2];                                       // dZ + channel offset, or nullptr (beyond Cout)
+    const char* bbase[2];                                       // segment base + channel offset, or nullptr (beyond T*K)
+    uint32_t bsb[2];                                            // pixel stride of that segment, bytes
+    int bdy[2], bdx[2], btoff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int co0 = co_tile * 128 + h * 64 + lp * 8;
+        abase[h] = co0 < a.Cout ? a.dz + (size_t)co0 * 2 : nullptr;
+        const int colv = col_tile * 16 + h * 8 + lp;
+        bbase[h] = nullptr; bsb[h] = 0; bdy[h] = bdx[h] = btoff[h] = 0;
+        if (colv < a.T * a.KV) {
+            const int t = colv / a.KV, cv = colv - t * a.KV;
+            const char* sp; int sst, coff;
+            pick_seg(a, cv, sp, sst, coff);
+            bbase[h] = sp + (size_t)coff * 16;
+            bsb[h] = (uint32_t)sst * 2u;
+            int ioy, iox;
+            decode_tap(a.taps[phase * a.T + t], bdy[h], bdx[h], ioy, iox);
+            btoff[h] = a.tapoff[phase * a.T + t];
+        }
+    }
+    const uint32_t asb = (uint32_t)a.dz_stride * 2u;
+    const int c_begin = split * a.chunks_per_split;
+    const int c_end = min(a.nchunks, c_begin + a.chunks_per_split);
+
+    const char* srcA[2][2];   // [pixel row i][sub-tile h]
+    const char* srcB[2][2];
+    auto prep = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = chunk * KC + r0 + 32 * i;
+            const bool on = chunk < c_end && m < a.M;
+            const uint32_t n = fdiv(on ? m : 0, a.fd_hw);
+            const uint32_t rem = (on ? m : 0) - n * (uint32_t)(a.Hg * a.Wg);
+            const uint32_t y = fdiv(rem, a.fd_w);
+            const uint32_t x = rem - y * a.Wg;
+            const uint32_t opix = (n * (uint32_t)a.Hy + y * a.osc + pa) * a.Wy + x * a.osc + pb;
+            const uint32_t ipix = n * (uint32_t)(a.Hx * a.Wx) + (uint32_t)a.isc * (y * a.Wx + x);
+            const uint32_t aoff = opix * asb;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                srcA[i][h] = (on && abase[h]) ? abase[h] + aoff : zero;
+                const bool ok = on && bbase[h] && (unsigned)((int)y + bdy[h]) < (unsigned)a.Hg && (unsigned)((int)x + bdx[h]) < (unsigned)a.Wg;
+                srcB[i][h] = ok ? bbase[h] + (uint32_t)((int)ipix + btoff[h]) * bsb[h] : zero;
+            }
+        }
+    };
+    auto fire = [&](int buf) {
+        char* st = smem + buf * STAGE + wave * 8 * 128;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)srcA[i][h], (lptr_t)(st + h * SUB + i * 32 * 128), 16, 0, 0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)srcB[i][h], (lptr_t)(st + (2 + h) * SUB + i * 32 * 128), 16, 0, 0);
+    };
+
+    // ---- fragment roles ---------------------------------------------------------------------------------------------
+    const int wr = wave >> 1, wc = wave & 1;                    // wave tile: 64 co x 64 columns
+    const int i16 = lane & 15, g = lane >> 4;
+    const int key = tr_key(i16), cg = tr_cg(i16), kb = g >> 1, chh = g & 1;
+    const int sw = (key >> 1) & 1;                              // pixel rows 2,3 (mod 4) keep their 64-byte halves swapped
+    int offA[2], offB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int inrow = ((i ^ sw) << 6) + chh * 32 + cg * 8;
+        offA[i] = wr * SUB + (kb * 8 + key) * 128 + inrow;
+        offB[i] = (2 + wc) * SUB + (kb * 8 + key) * 128 + inrow;
+    }
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) { prep(c_begin + s); fire(s); }
+    int rbuf = 0, wbuf = NS - 1;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        prep(chunk + NS - 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");
+        __builtin_amdgcn_s_barrier();
+        const uint32_t sT = lds_addr(smem) + rbuf * STAGE;
+        const uint32_t aA0 = sT + offA[0], aA1 = sT + offA[1], aB0 = sT + offB[0], aB1 = sT + offB[1];
+        Frag fa[2][2], fb[2][2];
+        tr_frag<0>(fa[0][0], aA0); tr_frag<0>(fa[0][1], aA1); tr_frag<0>(fb[0][0], aB0); tr_frag<0>(fb[0][1], aB1);
+        fire(wbuf);
+#define BTS_WTR_STEP(S, CUR, NXT, WAIT)                                                                             \
+        if (S + 1 < KC / 16) {                                                                                       \
+            tr_frag<(S + 1) % 4>(fa[NXT][0], aA0); tr_frag<(S + 1) % 4>(fa[NXT][1], aA1);                            \
+            tr_frag<(S + 1) % 4>(fb[NXT][0], aB0); tr_frag<(S + 1) % 4>(fb[NXT][1], aB1);                            \
+        }                                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" ::: "memory");        /* the 8 reads of k-step S have returned */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+                Mma<BF16>::run(frag_vec(fa[CUR][i]), frag_vec(fb[CUR][j]), acc[i][j]);                               \
+        __builtin_amdgcn_sched_barrier(0);
+        BTS_WTR_STEP(0, 0, 1, 8)
+        BTS_WTR_STEP(1, 1, 0, 8)
+        BTS_WTR_STEP(2, 0, 1, 8)
+        BTS_WTR_STEP(3, 1, 0, 0)
+#undef BTS_WTR_STEP
+        rbuf = rbuf + 1 == NS ? 0 : rbuf + 1;
+        wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // zero-page tail groups
+
+    // ---- epilogue: dw[co][phase*T*K + col] += acc (f32 atomics only join the few pixel splits) --------------------------
+    const size_t row_len = (size_t)a.Ttot * a.Ktot;
+    const int TK = a.T * a.Ktot;
+    const int frow = lane & 31, fk = lane >> 5;
+    const bool single = gridDim.y == 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = col_tile * 128 + (wc * 2 + j) * 32 + frow;
+        if (col >= TK) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_tile * 128 + (wr * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (co >= a.Cout) continue;
+                float* p = a.dw + (size_t)co * row_len + (size_t)phase * TK + col;
+                if (single) *p += acc[i][j][r];                 // dw arrives zeroed or holds an earlier contribution
+                else atomicAdd(p, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int launch_wgrad_tr(const ConvK& k0, hipStream_t st) {
+    ConvK k = k0;
+    if (k.Cout <= 64) return BTS_ERR_UNSUPPORTED;
+    if ((long)k.N * k.Hy * k.Wy * k.dz_stride * 2 >= (1l << 32)) return BTS_ERR_UNSUPPORTED;
+    k.n_co_tiles = ceil_div(k.Cout, 128);
+    k.n_col_tiles = ceil_div((long)k.T * k.Ktot, 128);
+    k.nchunks = ceil_div(k.M, KC);
+    const int tiles = k.n_co_tiles * k.n_col_tiles * k.nphase;
+    // split over pixels only until the chip is full: 2 workgroups per CU (64 KiB of LDS each) x 256 CUs
+    static const int target = [] { const char* e = getenv("BTS_WGRAD_TR_WGS"); return e ? atoi(e) : 512; }();   // A/B knob
+    int splits = target / tiles;
+    if (splits > k.nchunks / 4) splits = k.nchunks / 4;          // >= 4 chunks per workgroup
+    if (splits < 1) splits = 1;
+    k.chunks_per_split = ceil_div(k.nchunks, splits);
+    splits = ceil_div(k.nchunks, k.chunks_per_split);
+    dim3 grid(k.n_co_tiles * k.n_col_tiles, splits, k.nphase);
+    static DynLdsCache attr;
+    (void)attr;
+    hipLaunchKernelGGL(conv_wgrad_tr<2>, grid, dim3(256), 0, st, k);
+    if (hipGetLastError() != hipSuccess) return BTS_ERR_LAUNCH;
+    return BTS_OK;
+}
+
+}  // namespace bts_conv

@@ -126,6 +126,12 @@ CONV_CASES = [
     ("kmajor_dil", 72, [128], 9, 6, False, (2, 10, 14)),
     ("kmajor_up", 72, [128], 9, 1, True, (1, 6, 9)),
     ("kmajor_3seg_wide", 130, [64, 128, 64], 9, 1, False, (2, 7, 9)),
+    # wide bf16 weight gradients (conv_wgrad_tr: LDS-DMA + transposing reads): many pixel chunks, pixel splits joined by
+    # atomics, ragged Cout / K, sub-pixel phases, dilation, a 1x1 over a 3-segment concat
+    ("wtr_multi", 200, [64, 72], 9, 1, False, (2, 31, 45)),
+    ("wtr_up", 136, [128], 9, 1, True, (2, 17, 23)),
+    ("wtr_1x1", 256, [64, 128, 64], 1, 1, False, (2, 20, 31)),
+    ("wtr_dil", 128, [256], 9, 12, False, (1, 29, 40)),
 ]
 
 

@@ -193,7 +193,17 @@ def test_decoder_parity_at_bench_config(cfg, dt):
     if dt == torch.bfloat16:        # the kernels bench.py runs: fused chain forward + recompute backward, LDS-DMA convs
         assert any(n.startswith("lpg_head_chain_bwd") for n in names), names
         assert any(n.startswith("conv_igemm_dma<bf16") for n in names), names
-    out_bound, loss_bound, grad_bound = (1e-4, 1e-5, 1e-3) if dt == torch.float32 else (1e-2, 2e-3, 3e-2)
+    # Gradient bounds.  The only non-smooth ops of the decoder are the ReLUs of the dense ASPP (bts.py:51-66, 198); every
+    # other activation is ELU / sigmoid.  At this size ~1e-6 of the 13.7 M ReLU inputs per layer sit within f32 rounding of
+    # zero, so two correct f32 implementations take a handful of different masks and the gradients of everything at or
+    # upstream of the ASPP differ by ~1e-3 L2 -- measured, not assumed: tools/parity_probe.py against the oracle in f64
+    # (profiles/r02_parity_probe_c3.json) puts torch's own f32 evaluation 1.6e-3 from f64 on those tensors and the product
+    # 1.7e-3, while everything downstream of the ASPP (ELU only) is <= 1e-6 for both.  Hence 1e-4 where the function is
+    # smooth, 5e-3 upstream of the ReLUs, in f32; bf16 adds operand rounding on top.
+    out_bound, loss_bound, grad_bound = (1e-4, 1e-5, 1e-4) if dt == torch.float32 else (1e-2, 2e-3, 3e-2)
+    relu_bound = 5e-3 if dt == torch.float32 else 3e-2
+    smooth = ("daspp_conv", "reduc", "upconv3", "bn3", "conv3", "upconv2", "bn2", "conv2", "upconv1", "conv1", "get_depth",
+              "feat0", "feat1")
     rep = {"config": cfg, "dtype": str(dt), "outputs_l2": {}, "outputs_max": {}, "grads_l2": {}}
     for i, (o, r) in enumerate(zip(outs, ref)):
         rep["outputs_l2"]["out%d" % i] = l2rel(o, r)
@@ -217,5 +227,5 @@ def test_decoder_parity_at_bench_config(cfg, dt):
     else:
         assert max(rep["outputs_l2"].values()) < out_bound, rep["outputs_l2"]
     assert rep["loss"] < loss_bound
-    bad = {k: v for k, v in rep["grads_l2"].items() if not v < grad_bound}
+    bad = {k: v for k, v in rep["grads_l2"].items() if not v < (grad_bound if k.startswith(smooth) else relu_bound)}
     assert not bad, bad

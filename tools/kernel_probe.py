@@ -35,6 +35,47 @@ def timeit(fn, iters):
     return s.elapsed_time(e) / iters * 1e-3
 
 
+def timeit_rot(fns, iters):
+    """Like timeit, but cycles through `fns` (same kernel on DIFFERENT buffers, together > 512 MB) and keeps every
+    returned tensor alive until the next lap, so neither inputs nor outputs of a launch can still sit in the 256 MiB
+    Infinity Cache from the previous one: the rate it reports is an HBM rate (MI355X_MICROARCH.md, Infinity Cache)."""
+    keep = [fn() for fn in fns]
+    torch.cuda.synchronize()
+    laps = max(1, (iters + len(fns) - 1) // len(fns))
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(laps):
+        for i, fn in enumerate(fns):
+            keep[i] = fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / (laps * len(fns)) * 1e-3
+
+
+def lpg_case_rot(B, H, W, k, iters, footprint=768 << 20):
+    """LPG op / fused head at one shape with a rotating working set (HBM-resident numbers)."""
+    h, w = H // k, W // k
+    per = B * H * W * 4 * 2 + B * h * w * 16 * 2
+    nrot = max(2, (footprint + per - 1) // per)
+    raws = [torch.randn(B, h, w, 4, device=DEV) for _ in range(nrot)]
+    gs = [torch.randn(B, H, W, device=DEV) for _ in range(nrot)]
+    out = []
+    tag = "k=%d B=%d %dx%d rot%d" % (k, B, H, W, nrot)
+    t = timeit_rot([(lambda r=r: ops.lpg_head_fwd(r, k, 80.0)) for r in raws], iters)
+    byts = B * h * w * (16 + 4 * k * k)
+    out.append(dict(case="lpg_head_fwd " + tag, sec=t, alg_gbs=byts / t / 1e9, alg_bytes=byts, hbm_resident=True))
+    t = timeit_rot([(lambda r=r, g=g: ops.lpg_head_bwd(r, g, k, 80.0, torch.bfloat16, 8)) for r, g in zip(raws, gs)], iters)
+    byts = B * h * w * (16 + 4 * k * k + 16)
+    out.append(dict(case="lpg_head_bwd " + tag, sec=t, alg_gbs=byts / t / 1e9, alg_bytes=byts, hbm_resident=True))
+    t = timeit_rot([(lambda r=r: ops.lpg_fwd(r, k)) for r in raws], iters)
+    byts = B * H * W * 4 * (1 + 4.0 / (k * k))
+    out.append(dict(case="lpg_op_fwd " + tag, sec=t, alg_gbs=byts / t / 1e9, alg_bytes=byts, hbm_resident=True))
+    t = timeit_rot([(lambda r=r, g=g: ops.lpg_bwd(g, r, k)) for r, g in zip(raws, gs)], iters)
+    byts = B * H * W * 4 * (1 + 8.0 / (k * k))
+    out.append(dict(case="lpg_op_bwd " + tag, sec=t, alg_gbs=byts / t / 1e9, alg_bytes=byts, hbm_resident=True))
+    return out
+
+
 def conv_case(name, dt, cout, segc, kk, dil, up, N, H, W, iters, which):
     L = ConvLayer(name, cout, segc, kk, dil, up)
     v = 4 if dt == torch.float32 else 8
@@ -56,6 +97,12 @@ def conv_case(name, dt, cout, segc, kk, dil, up, N, H, W, iters, which):
         dz = torch.randn(N, Ho, Wo, cp, device=DEV).to(dt)
         t = timeit(lambda: L.wgrad(segs, dz), iters)
         res.append(dict(case=name + ".wgrad(+zero,unpack)", dtype=str(dt), sec=t, tflops=flops / t / 1e12))
+    if "wgradk" in which:      # the weight-gradient kernel alone, into a caller-zeroed packed buffer (no memset, no unpack)
+        dz = torch.randn(N, Ho, Wo, cp, device=DEV).to(dt)
+        tb = L.tables(dt, dz.device)
+        dwp = torch.zeros((cout, L.nphase * L.T, tb["ktot"]), dtype=torch.float32, device=DEV)
+        t = timeit(lambda: L.wgrad_packed(segs, dz, dwp), iters)
+        res.append(dict(case=name + ".wgrad_kernel", dtype=str(dt), sec=t, tflops=flops / t / 1e12))
     if "dgrad" in which:
         dz = torch.randn(N, Ho, Wo, cp, device=DEV).to(dt)
         wd = L.pack_dgrad(w, dt, 0)
@@ -147,7 +194,7 @@ def misc_cases(B, H, W, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--set", default="all", help="all | conv | fwd | narrow | lpg | chain | misc")
+    ap.add_argument("--set", default="all", help="all | conv | fwd | mid | wgrad | narrow | pmc | lpg | lpgrot | chain | misc")
     a = ap.parse_args()
     bf, f32 = torch.bfloat16, torch.float32
     res = []
@@ -188,6 +235,17 @@ def main():
         res += conv_case("conv1", bf, 32, [32, 4], 9, 1, False, B, 352, 1216, a.iters, ("fwd", "wgrad"))
         res += conv_case("get_depth", bf, 1, [32], 9, 1, False, B, 352, 1216, a.iters, ("wgrad",))
         res += chain_cases(8, 352, 1216, bf, a.iters)
+    if a.set == "wgrad":    # wide-layer weight gradients, kernel alone (A/B: BTS_WGRAD_TR=0|1 in separate processes)
+        B = 8
+        res += conv_case("conv5", bf, 512, [512, 384], 9, 1, False, B, 22, 76, a.iters, ("wgradk",))
+        res += conv_case("upconv5", bf, 512, [2208], 9, 1, True, B, 11, 38, a.iters, ("wgradk",))
+        res += conv_case("conv4", bf, 256, [256, 192], 9, 1, False, B, 44, 152, a.iters, ("wgradk",))
+        res += conv_case("upconv4", bf, 256, [512], 9, 1, True, B, 22, 76, a.iters, ("wgradk",))
+        res += conv_case("daspp_conv", bf, 128, [256, 128, 128, 128, 128, 128], 9, 1, False, B, 44, 152, a.iters, ("wgradk",))
+        res += conv_case("daspp12_3x3", bf, 128, [256], 9, 12, False, B, 44, 152, a.iters, ("wgradk",))
+        res += conv_case("daspp1x1_24", bf, 256, [256, 192, 128, 128, 128, 128], 1, 1, False, B, 44, 152, a.iters, ("wgradk",))
+        res += conv_case("conv3", bf, 128, [128, 96, 1], 9, 1, False, B, 88, 304, a.iters, ("wgradk",))
+        res += conv_case("upconv3", bf, 128, [128], 9, 1, True, B, 44, 152, a.iters, ("wgradk",))
     if a.set == "narrow":   # full-resolution narrow layers: weight gradients
         B = 8
         res += conv_case("get_depth", bf, 1, [32], 9, 1, False, B, 352, 1216, a.iters, ("wgrad",))
@@ -200,6 +258,11 @@ def main():
             res += lpg_case(8, 352, 1216, k, a.iters)      # train shape (configs[2], per GPU)
         for k in (8, 4, 2):
             res += lpg_case(32, 704, 1216, k, a.iters)     # inference shape (configs[4])
+    if a.set in ("all", "lpgrot"):   # the same LPG kernels with a rotating > 512 MB working set: HBM rates, not cache rates
+        for k in (8, 4, 2):
+            res += lpg_case_rot(8, 352, 1216, k, max(a.iters, 40))
+        for k in (8, 4, 2):
+            res += lpg_case_rot(32, 704, 1216, k, max(a.iters, 12))
     if a.set in ("all", "chain"):
         res += chain_cases(8, 352, 1216, bf, a.iters)
         res += chain_cases(32, 704, 1216, bf, a.iters)
