@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK a) {
 // buffer; a counted s_waitcnt vmcnt((NS-2)*G) (G = DMA instructions per thread per chunk) retires
 // exactly chunk c's group and leaves the younger groups in flight ACROSS the raw s_barrier (a plain
 // __syncthreads() would drain them: hipcc emits vmcnt(0) in front of it while an LDS-DMA is pending).
-template <typename T, int WR, int WC, int TM, int TN, int NS>
+template <typename T, int WR, int WC, int TM, int TN, int NS, int PF = 1>
 __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
     constexpr int NW = WR * WC;                       // waves per workgroup
     constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
@@ -427,27 +427,95 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");   // this wave's part of `chunk` has landed
         __builtin_amdgcn_s_barrier();                                          // everyone's has; buffer wbuf is free
         const char* sT = smem + rbuf * BUF;
-        u32x4_t fa[2][TM], fb[2][TN];
-        // k-step 0 fragments first (their LDS latency overlaps the DMA issue), then one k-step of read-ahead
+        if constexpr (PF >= 6) {
+            // Whole-chunk fragment prefetch with the LDS reads issued from inline asm and COUNTED lgkmcnt waits.  hipcc waits
+            // lgkmcnt(0) at the first MFMA behind a batch of LDS-DMA instructions (it did so in the read-ahead form above as
+            // well: the "read-ahead" k-step was always waited for together with the current one), so with compiler-visible
+            // loads every chunk pays the full LDS queueing latency of its last read.  Here 4 x (TM+TN) reads are in flight
+            // and k-step s starts as soon as ITS reads are back (in-order return): lgkmcnt(3R), (2R), (R), (0).
+            constexpr int R = TM + TN;
+            static_assert(4 * R - 1 <= 15, "lgkmcnt range");
+            const uint32_t sTa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem + rbuf * BUF;
+            u32x4_t fa[4][TM], fb[4][TN];
+            auto rd = [&](u32x4_t& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); };
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[0][i] = *(const u32x4_t*)(sT + offA[i] + (((0 + fk) ^ swz) << 4));
+            for (int i = 0; i < TM; ++i) rd(fa[0][i], sTa + offA[i] + (((0 + fk) ^ swz) << 4));
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[0][j] = *(const u32x4_t*)(sT + offB[j] + (((0 + fk) ^ swz) << 4));
-        fire_chunk(wbuf);
+            for (int j = 0; j < TN; ++j) rd(fb[0][j], sTa + offB[j] + (((0 + fk) ^ swz) << 4));
+            fire_chunk(wbuf);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s < 3) {
+            for (int s = 1; s < 4; ++s) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[(s + 1) & 1][i] = *(const u32x4_t*)(sT + offA[i] + (((2 * (s + 1) + fk) ^ swz) << 4));
+                for (int i = 0; i < TM; ++i) rd(fa[s][i], sTa + offA[i] + (((2 * s + fk) ^ swz) << 4));
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[(s + 1) & 1][j] = *(const u32x4_t*)(sT + offB[j] + (((2 * (s + 1) + fk) ^ swz) << 4));
+                for (int j = 0; j < TN; ++j) rd(fb[s][j], sTa + offB[j] + (((2 * s + fk) ^ swz) << 4));
             }
-            __builtin_amdgcn_sched_barrier(0);   // keep the read-ahead ABOVE this k-step's MFMAs (hipcc sinks it otherwise)
+            if constexpr (PF >= 7) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int s = 0; s < 4; ++s) {
+                if (s == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 * R) : "memory");
+                else if (s == 1) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * R) : "memory");
+                else if (s == 2) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(R) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) Mma<T>::run(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa[s][i], fb[s][j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (PF >= 7) __builtin_amdgcn_s_setprio(0);
+        } else if constexpr (PF >= 4) {
+            // Whole-chunk fragment prefetch (A/B variant, BTS_CONV_PF): all 4 k-steps' fragments are requested right behind
+            // the barrier (16 ds_read_b128 per wave), the MFMAs then only wait for counted lgkmcnt, so the LDS queueing
+            // latency of two co-resident workgroups (8 waves x 4 KiB per k-step) is paid once per chunk instead of per k-step.
+            u32x4_t fa[4][TM], fb[4][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = *(const u32x4_t*)(sT + offA[i] + (((0 + fk) ^ swz) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = *(const u32x4_t*)(sT + offB[j] + (((0 + fk) ^ swz) << 4));
+            fire_chunk(wbuf);
+#pragma unroll
+            for (int s = 1; s < 4; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[s][i] = *(const u32x4_t*)(sT + offA[i] + (((2 * s + fk) ^ swz) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[s][j] = *(const u32x4_t*)(sT + offB[j] + (((2 * s + fk) ^ swz) << 4));
+            }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PF >= 5) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa[s][i], fb[s][j], acc[i][j]);
+            }
+            if constexpr (PF >= 5) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            u32x4_t fa[2][TM], fb[2][TN];
+            // k-step 0 fragments first (their LDS latency overlaps the DMA issue), then one k-step of read-ahead
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = *(const u32x4_t*)(sT + offA[i] + (((0 + fk) ^ swz) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = *(const u32x4_t*)(sT + offB[j] + (((0 + fk) ^ swz) << 4));
+            fire_chunk(wbuf);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s < 3) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[(s + 1) & 1][i] = *(const u32x4_t*)(sT + offA[i] + (((2 * (s + 1) + fk) ^ swz) << 4));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[(s + 1) & 1][j] = *(const u32x4_t*)(sT + offB[j] + (((2 * (s + 1) + fk) ^ swz) << 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the read-ahead ABOVE this k-step's MFMAs (hipcc sinks it otherwise)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         rbuf = rbuf + 1 == NS ? 0 : rbuf + 1;
         wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;
@@ -1641,6 +1709,10 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
             else if (big == 'd') go2(conv_igemm_dma<T, 2, 4, 2, 2, 2>, 128, 256, 512);
             else if (big == 'e' && k.Cout >= 256) go2(conv_igemm_dma<T, 2, 4, 4, 2, 2>, 256, 256, 512);   // experimental, see DESIGN §10
             else if (big == 'e') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2>, 128, 128, 256);
+            else if (big == 'p') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 4>, 128, 128, 256);    // whole-chunk fragment prefetch
+            else if (big == 'q') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 5>, 128, 128, 256);    // + s_setprio around the MFMA block
+            else if (big == 'r') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 6>, 128, 128, 256);    // asm reads, counted lgkmcnt
+            else if (big == 's') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 7>, 128, 128, 256);    // + s_setprio
             else go2(conv_igemm_dma<T, 2, 2, 2, 2, 2>, 128, 128, 256);
         }
         else if (k.Cout > 32) go2(conv_igemm_dma<T, 1, 4, 2, 1, 2>, 64, 128, 256);

@@ -16,14 +16,15 @@ __device__ __forceinline__ u32x2 tr_read(uint32_t addr) {
 // groups at +32 B.  pattern 2: same with rows (i&3), col group (i>>2).
 __global__ void sem_kernel(uint16_t* out, int pattern) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[8192];
-    for (int i = threadIdx.x; i < 8192; i += 64) lds[i] = (uint16_t)i;
+    for (int i = threadIdx.x; i < 8192; i += 64) ((volatile uint16_t*)lds)[i] = (uint16_t)i;   // volatile: the asm read is invisible to DSE
     __syncthreads();
     const int l = threadIdx.x, i = l & 15, g = l >> 4;
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)lds;
     uint32_t addr;
     if (pattern == 0) addr = l * 8;
     else if (pattern == 1) addr = (i >> 2) * 128 + (i & 3) * 8 + g * 32;
     else addr = (i & 3) * 128 + (i >> 2) * 8 + g * 32;
-    u32x2 v = tr_read(addr);
+    u32x2 v = tr_read(base + addr);
     out[l * 4 + 0] = v.x & 0xffff; out[l * 4 + 1] = v.x >> 16; out[l * 4 + 2] = v.y & 0xffff; out[l * 4 + 3] = v.y >> 16;
 }
 
@@ -83,16 +84,5 @@ int main() {
             if (p > 0 && l == 15) { printf("  ...\n"); l = 47; }
         }
     }
-    uint32_t* c; hipMalloc(&c, 4096 * 4);
-    uint32_t hc[4096];
-    for (int rowmap = 0; rowmap < 2; ++rowmap)
-        for (int layout = 0; layout < 5; ++layout) {
-            time_kernel<<<512, 256>>>(c, layout, rowmap);
-            hipDeviceSynchronize();
-            time_kernel<<<512, 256>>>(c, layout, rowmap);
-            hipMemcpy(hc, c, 2048 * 4, hipMemcpyDeviceToHost);
-            double s = 0; for (int i = 0; i < 2048; ++i) s += hc[i];
-            printf("layout %d rowmap %d: %.1f cycles per wave-instruction (4 waves/CU x2 blocks)\n", layout, rowmap, s / 2048 / (256 * 16));
-        }
     return 0;
 }
