@@ -131,6 +131,77 @@ static __device__ const uint32_t kZeroPage[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+template <typename T, int WR, int WC, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16_t (&acc)[TM][TN], int co_tile, int px_tile, int phase,
+                                              int wr, int wc, int frow, int fk) {
+    constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+    // ---- epilogue: lanes <-> pixels, registers <-> channels -------------------------------
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int m = px_tile * BN + (wc * TN + j) * 32 + frow;
+        if (m >= a.M) continue;
+        const uint32_t n = fdiv(m, a.fd_hw);
+        const uint32_t rem = m - n * (uint32_t)(a.Hg * a.Wg);
+        const uint32_t y = fdiv(rem, a.fd_w);
+        const uint32_t x = rem - y * a.Wg;
+        const size_t opix = ((size_t)n * a.Hy + (y * a.osc + (phase >> 1))) * a.Wy + (x * a.osc + (phase & 1));
+        float sc = a.out_scale;
+        if (a.out_scale_n) sc *= a.out_scale_n[n];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = co_tile * BM + (wr * TM + i) * 32 + 8 * q + 4 * fk;
+                if (co >= a.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[i][j][4 * q + e];
+                    if (a.act == BTS_ACT_ELU) t = act_elu(t);
+                    else if (a.act == BTS_ACT_SIGMOID) t = act_sigmoid(t);
+                    else if (a.act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
+                    v[e] = t * sc;
+                }
+                const size_t o = opix * a.y_stride + co;
+                if (a.vec_store) {
+                    if (a.y_f32) {
+                        float* p = (float*)a.y + o;
+                        f32x4_t t = {v[0], v[1], v[2], v[3]};
+                        if (a.accumulate) { f32x4_t old = *(f32x4_t*)p; t += old; }
+                        *(f32x4_t*)p = t;
+                    } else {
+                        uint16_t* p = (uint16_t*)a.y + o;
+                        if (a.accumulate) {
+                            u32x2_t old = *(u32x2_t*)p;
+                            v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                            v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+                        }
+                        u32x2_t t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *(u32x2_t*)p = t;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e >= a.Cout) break;
+                        if (a.y_f32) {
+                            float* p = (float*)a.y + o + e;
+                            *p = a.accumulate ? *p + v[e] : v[e];
+                        } else {
+                            uint16_t* p = (uint16_t*)a.y + o + e;
+                            const float t = a.accumulate ? bf16_bits_to_f32(*p) + v[e] : v[e];
+                            *p = (uint16_t)f32_to_bf16_bits(t);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// conv_igemm_pp.hip: forward / data-gradient of the wide bf16 layers with two staggered wave groups per workgroup; returns
+// BTS_ERR_UNSUPPORTED outside its domain (the caller then uses conv_igemm_dma).
+int launch_fwd_pp(const ConvK& k, hipStream_t st, int variant);
+
 // conv_wgrad_tr.hip: bf16 weight gradient of the wide layers (LDS-DMA staging + transpose reads); returns BTS_ERR_UNSUPPORTED
 // when the shape is outside its domain (the caller then falls back to conv_wgrad).
 int launch_wgrad_tr(const ConvK& k, hipStream_t st);

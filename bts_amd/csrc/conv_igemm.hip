@@ -23,73 +23,6 @@ namespace {
 
 using namespace bts_conv;
 
-template <typename T, int WR, int WC, int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16_t (&acc)[TM][TN], int co_tile, int px_tile, int phase,
-                                              int wr, int wc, int frow, int fk) {
-    constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
-    // ---- epilogue: lanes <-> pixels, registers <-> channels -------------------------------
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int m = px_tile * BN + (wc * TN + j) * 32 + frow;
-        if (m >= a.M) continue;
-        const uint32_t n = fdiv(m, a.fd_hw);
-        const uint32_t rem = m - n * (uint32_t)(a.Hg * a.Wg);
-        const uint32_t y = fdiv(rem, a.fd_w);
-        const uint32_t x = rem - y * a.Wg;
-        const size_t opix = ((size_t)n * a.Hy + (y * a.osc + (phase >> 1))) * a.Wy + (x * a.osc + (phase & 1));
-        float sc = a.out_scale;
-        if (a.out_scale_n) sc *= a.out_scale_n[n];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int co = co_tile * BM + (wr * TM + i) * 32 + 8 * q + 4 * fk;
-                if (co >= a.Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[i][j][4 * q + e];
-                    if (a.act == BTS_ACT_ELU) t = act_elu(t);
-                    else if (a.act == BTS_ACT_SIGMOID) t = act_sigmoid(t);
-                    else if (a.act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
-                    v[e] = t * sc;
-                }
-                const size_t o = opix * a.y_stride + co;
-                if (a.vec_store) {
-                    if (a.y_f32) {
-                        float* p = (float*)a.y + o;
-                        f32x4_t t = {v[0], v[1], v[2], v[3]};
-                        if (a.accumulate) { f32x4_t old = *(f32x4_t*)p; t += old; }
-                        *(f32x4_t*)p = t;
-                    } else {
-                        uint16_t* p = (uint16_t*)a.y + o;
-                        if (a.accumulate) {
-                            u32x2_t old = *(u32x2_t*)p;
-                            v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
-                            v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
-                        }
-                        u32x2_t t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                        *(u32x2_t*)p = t;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (co + e >= a.Cout) break;
-                        if (a.y_f32) {
-                            float* p = (float*)a.y + o + e;
-                            *p = a.accumulate ? *p + v[e] : v[e];
-                        } else {
-                            uint16_t* p = (uint16_t*)a.y + o + e;
-                            const float t = a.accumulate ? bf16_bits_to_f32(*p) + v[e] : v[e];
-                            *p = (uint16_t)f32_to_bf16_bits(t);
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------------
@@ -596,7 +529,10 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sW + (pass * RP + wave * 8) * 128), 16, 0, 0);
         }
     };
-    auto compute = [&](const char* sP, f32x16_t (&acc)[NG]) {
+    // nks: k-steps of this channel chunk that hold real channels (2 vectors each); the rest of the 128-byte row is zero
+    // fill (conv1: 40 of 64 channels, get_depth / the conv1 data-gradients: 32, get_depth's data-gradient: 8), so skipping
+    // it changes nothing but the MFMA and ds_read count
+    auto compute = [&](const char* sP, f32x16_t (&acc)[NG], int nks) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
 #pragma unroll
@@ -608,6 +544,7 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
                 const int pswz = (prow >> 1) & 7, wswz = (wrow >> 1) & 7;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
+                    if (s >= nks) break;
                     const u32x4_t fb = *(const u32x4_t*)(sP + prow * 128 + (((2 * s + fk) ^ pswz) << 4));
                     const u32x4_t fa = *(const u32x4_t*)(sW + wrow * 128 + (((2 * s + fk) ^ wswz) << 4));
                     Mma<T>::run(fa, fb, acc[g]);
@@ -696,7 +633,7 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
             for (int g = 0; g < NG; ++g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-            compute(smem + cur * PR_PAD * 128, acc);
+            compute(smem + cur * PR_PAD * 128, acc, (min(a.KV, 8) + 1) >> 1);
             epilogue(acc, n, y0, x0);
             n = nn; y0 = ny0; x0 = nx0;
         }
@@ -713,7 +650,7 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
             dma_weights(cc);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            compute(smem, acc);
+            compute(smem, acc, (min(a.KV - cc * 8, 8) + 1) >> 1);
             __syncthreads();      // patch / weights are overwritten by the next chunk
         }
         epilogue(acc, n, y0, x0);
@@ -1703,6 +1640,10 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
         //   c  128co x 256px, 8 waves, 3 stages (144 KiB)                           [r1: = d; depth is not the limiter]
         //   64co x 128px and 32co x 256px, 4 waves, 2 stages for narrow layers
         static const char big = [] { const char* e = getenv("BTS_CONV_BIG"); return e ? e[0] : 'a'; }();   // A/B knob (a = default)
+        if (k.Cout > 64 && T::kBytes == 2 && (big == 'x' || big == 'y')) {     // staggered wave groups (conv_igemm_pp.hip)
+            const int rc = launch_fwd_pp(k, st, (big == 'y' && k.Cout >= 256) ? 4 : 2);
+            if (rc != BTS_ERR_UNSUPPORTED) return rc;
+        }
         if (k.Cout > 64) {
             if (big == 'b') go2(conv_igemm_dma<T, 2, 2, 2, 2, 3>, 128, 128, 256);
             else if (big == 'c') go2(conv_igemm_dma<T, 2, 4, 2, 2, 3>, 128, 256, 512);
