@@ -54,7 +54,12 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="infer = BASELINE.json configs[4]: no-grad forward, DenseNet161 704x1216 batch 32 (secondary config)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for plumbing tests")
-    ap.add_argument("--reducer", default="ddp", choices=["ddp", "bts"], help="ddp = torch DDP, bts = bts_amd.parallel.GradAllReducer")
+    ap.add_argument("--reducer", default="auto", choices=["auto", "ddp", "bts", "bts-graph"],
+                    help="N>1 gradient exchange: ddp = torch DDP (eager step, exchange overlapped with backward); bts = "
+                         "bts_amd.parallel.GradAllReducer from hooks (eager, overlapped); bts-graph = hipGraph(fwd+bwd) -> "
+                         "GradAllReducer.reduce_all() -> hipGraph(AdamW); auto = bts (the eager step is GPU-bound: 61.1 ms eager vs 60.9 ms "
+                         "replayed at N=1, and bts costs +1.2 ms at world 1 against +3.1 ms for ddp and +3.2 ms for bts-graph)")
+    ap.add_argument("--force-dist", type=int, default=0, help=argparse.SUPPRESS)   # world-1 process group: exercises the N>1 path on one GPU
     return ap.parse_args()
 
 
@@ -241,8 +246,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    multi = world > 1 or bool(args.force_dist)
     if world > 1:
         dist.init_process_group(backend=args.backend, init_method="env://")
+    elif multi:
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        dist.init_process_group(backend=args.backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     local = local % torch.cuda.device_count()      # (plumbing tests run several ranks on one GPU over gloo)
     torch.cuda.set_device(local)
@@ -265,16 +278,20 @@ def main():
         model.encoder.to(memory_format=torch.channels_last)
     net = model
     reducer = None
-    if world > 1 and args.reducer == "ddp":
+    red_mode = args.reducer
+    if red_mode == "auto":
+        red_mode = "bts"      # hook-driven GradAllReducer, eager step: measured fastest N>1 form (profiles/r02_bench_dist_world1.md)
+    if multi and red_mode == "ddp":
         # ResNet-family backbones carry the unused torchvision head (avgpool/fc): bts_main.py:352 sets find_unused_parameters
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
                                                         broadcast_buffers=False,
                                                         find_unused_parameters="resne" in args.encoder)
-    elif world > 1:
+    elif multi:
         from bts_amd.parallel import GradAllReducer, broadcast_parameters
         broadcast_parameters(model)
-        reducer = GradAllReducer(model.parameters())
-    use_graph = bool(args.graph) and world == 1
+        reducer = GradAllReducer(model.parameters(), reduce_single=bool(args.force_dist))
+    use_graph = bool(args.graph) and not multi
+    split_graph = multi and red_mode == "bts-graph"
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
     lr_t = torch.tensor(1e-4, device=dev)      # capturable optimizers read lr from a device tensor
     groups = [{"params": [p for p in model.encoder.parameters() if p.requires_grad], "weight_decay": 1e-2},
@@ -313,6 +330,19 @@ def main():
             opt.step()
         return loss
 
+    # split form for N > 1 (bts-graph): A = zero + forward + loss + backward with the reducer's hooks deferred, B = optimizer
+    def step_fwd_bwd():
+        reducer.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
+            outs = net(image, focal)
+        loss = crit(outs[4], gt, mask)
+        with reducer.no_sync():
+            loss.backward()
+        return loss
+
+    def step_opt():
+        opt.step(prepared=True)
+
     def set_lr():
         lr = poly_lr()
         if own_opt:
@@ -349,11 +379,40 @@ def main():
             graph, graph_note = None, "eager (graph capture failed: %s)" % str(e)[:120]
             torch.cuda.synchronize()
 
+    graph_b = None
+    if split_graph and own_opt and reducer is not None:
+        # N > 1: the collective stays OUTSIDE the graphs (nothing of RCCL is captured): replay(fwd+bwd) -> 3 all-reduces of
+        # the flat gradient buckets on the same stream -> replay(AdamW).  Falls back to the eager DDP-style step on any error.
+        try:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                set_lr()
+                step_fwd_bwd()
+                reducer.reduce_all()
+                step_opt()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = step_fwd_bwd()
+            graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_b):
+                step_opt()
+            graph_note = "hipGraph replay (fwd+loss+bwd) -> GradAllReducer.reduce_all over %s -> hipGraph replay (AdamW)" % args.backend
+        except Exception as e:   # noqa: BLE001
+            graph, graph_b, graph_note = None, None, "eager (split graph capture failed: %s)" % str(e)[:120]
+            torch.cuda.synchronize()
+
     def step():
         if graph is None:
             return step_eager()
         set_lr()
         graph.replay()
+        if graph_b is not None:
+            reducer.reduce_all()
+            graph_b.replay()
         gstep[0] += 1
         return static_loss
 
@@ -377,10 +436,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss.item())
-    if graph is not None and not args.no_kernel_events and rank == 0:
+    if graph is not None and not args.no_kernel_events and (rank == 0 or world > 1):
         # events cannot be recorded inside a graph replay: time the same kernels over the same number of
-        # eager steps right after the timed region (same process, same buffers, same clocks)
-        prof = profiler.enable()
+        # eager steps right after the timed region (same process, same buffers, same clocks).  With N > 1 every rank runs
+        # these steps (their collectives must match); only rank 0 records.
+        if rank == 0:
+            prof = profiler.enable()
         for _ in range(args.steps):
             step_eager()
         torch.cuda.synchronize()
@@ -399,7 +460,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s train step (fwd+silog+bwd+AdamW), %dx%d, %d img/GPU, kitti focal scaling" %
                        (args.encoder, args.height, args.width, args.batch),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "grad_exchange": ("none" if world == 1 else ("torch DDP over %s" % args.backend if reducer is None else "bts GradAllReducer over %s" % args.backend)),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "grad_exchange": ("none" if not multi else ("torch DDP over %s" % args.backend if reducer is None else "bts GradAllReducer over %s" % args.backend)),
                        "encoder": "stock PyTorch-ROCm (%s autocast)" % args.dtype, "decoder": "HIP kernels via libbts_amd.so", "launch": graph_note, "optimizer": "bts_adamw_step (fused HIP)" if own_opt else "torch.optim.AdamW(fused)",
                        "final_loss": round(final_loss, 5)},
         }

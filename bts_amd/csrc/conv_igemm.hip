@@ -1638,10 +1638,18 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
         //      rate, so the tile shape, not the schedule, caps it.  A/B only (BTS_CONV_BIG=e).
         //   b  128co x 128px, 4 waves, 3 stages ( 96 KiB, 1 WG/CU = 1 wave/SIMD)   [r1: 339-368 TF: too few waves]
         //   c  128co x 256px, 8 waves, 3 stages (144 KiB)                           [r1: = d; depth is not the limiter]
+        //   p/q whole-chunk fragment prefetch with compiler-visible loads (+ s_setprio): hipcc waits lgkmcnt(0) behind a DMA batch, so
+        //      all 16 reads are waited for before the first MFMA: +-0 %
+        //   r/s the same with the ds_read_b128 issued from inline asm and counted lgkmcnt(12/8/4/0) (+ s_setprio 1 around the 16
+        //      MFMAs): +3..10 % per layer over a on one box (r2: conv5 713 -> 749 TF, conv4 dgrad 578 -> 638, conv3 490 -> 517,
+        //      daspp_conv 712 -> 748).  DEFAULT = s.
+        //   x/y/z conv_igemm_pp.hip: two staggered wave groups, 128x256 (x, z = DMA issue between the MFMAs) / 256x256 (y): parity-
+        //      green, slower (x: -8 %) or layer-dependent (y: conv4 +8 %, conv5 -38 %); see DESIGN section 9 (the LDS-DMA fill rate of
+        //      ~20 B/clk/CU, not the overlap structure, is the limiter, and 256-wide tiles do not fill 256 CUs at these shapes)
         //   64co x 128px and 32co x 256px, 4 waves, 2 stages for narrow layers
-        static const char big = [] { const char* e = getenv("BTS_CONV_BIG"); return e ? e[0] : 'a'; }();   // A/B knob (a = default)
-        if (k.Cout > 64 && T::kBytes == 2 && (big == 'x' || big == 'y')) {     // staggered wave groups (conv_igemm_pp.hip)
-            const int rc = launch_fwd_pp(k, st, (big == 'y' && k.Cout >= 256) ? 4 : 2);
+        static const char big = [] { const char* e = getenv("BTS_CONV_BIG"); return e ? e[0] : 's'; }();   // A/B knob (s = default)
+        if (k.Cout > 64 && T::kBytes == 2 && (big == 'x' || big == 'y' || big == 'z')) {     // staggered wave groups (conv_igemm_pp.hip)
+            const int rc = launch_fwd_pp(k, st, big == 'z' ? 3 : (big == 'y' && k.Cout >= 256) ? 4 : 2);
             if (rc != BTS_ERR_UNSUPPORTED) return rc;
         }
         if (k.Cout > 64) {
@@ -1654,7 +1662,8 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
             else if (big == 'q') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 5>, 128, 128, 256);    // + s_setprio around the MFMA block
             else if (big == 'r') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 6>, 128, 128, 256);    // asm reads, counted lgkmcnt
             else if (big == 's') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 7>, 128, 128, 256);    // + s_setprio
-            else go2(conv_igemm_dma<T, 2, 2, 2, 2, 2>, 128, 128, 256);
+            else if (big == 'a') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2>, 128, 128, 256);       // round-1 schedule (compiler-placed waits)
+            else go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 7>, 128, 128, 256);                    // default: s
         }
         else if (k.Cout > 32) go2(conv_igemm_dma<T, 1, 4, 2, 1, 2>, 64, 128, 256);
         else go2(conv_igemm_dma<T, 1, 4, 1, 2, 2>, 32, 256, 256);

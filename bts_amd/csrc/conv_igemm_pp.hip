@@ -29,7 +29,7 @@
 namespace bts_conv {
 namespace {
 
-template <int TMW>
+template <int TMW, bool ILV>
 __global__ __launch_bounds__(512) void conv_igemm_pp(const ConvK a) {
     using T = BF16;
     constexpr int BM = 2 * TMW * 32, BN = 256;
@@ -261,7 +261,33 @@ __global__ __launch_bounds__(512) void conv_igemm_pp(const ConvK a) {
 
     int rbuf = 0, wbuf = NS - 1;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        if constexpr (NS == 3) {
+        if constexpr (NS == 3 && ILV) {
+            // Interleaved form: the LOAD section only reads fragments; address generation and the DMA issue of chunk c+2 sit
+            // BETWEEN the MFMAs of MFMA(c) (one MFMA leaves ~28 idle issue cycles on its wave), pinned there by
+            // sched_group_barrier.  Chunk c+2's stage last held chunk c-1 (read in phases 2c-2 / 2c-1; this section is
+            // phase 2c+1 / 2c+2); its pieces are waited for at the end of LOAD(c+1) and first read in LOAD(c+2).
+            read_section(rbuf, 0);
+            end_load(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            prep_chunk(chunk + 2);
+            fire_chunk(wbuf);
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa[s][i], fb[s][j], acc[i][j]);
+#pragma unroll
+            for (int q = 0; q < KS * TMW * TN; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);     // up to six VALU / SALU behind it
+                if (q % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a DMA issue every third MFMA
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        } else if constexpr (NS == 3) {
             // LOAD(c) [group 0: phase 2c, group 1: 2c+1] | MFMA(c).  Stage of chunk c+2 last held chunk c-1, whose reads ended
             // (lgkmcnt(0)) before the barriers closing phases 2c-2 / 2c-1: both lie before this section.  vmcnt(G) retires this
             // wave's pieces of chunk c+1 (issued a whole chunk period ago) and leaves chunk c+2's in flight; chunk c+1 is first
@@ -306,13 +332,19 @@ int launch_fwd_pp(const ConvK& k0, hipStream_t st, int variant) {
     dim3 grid(k.n_co_tiles * k.n_px_tiles, k.nphase);
     const int NS = variant == 4 ? 2 : 3;
     const int lds = NS * (BM + 256) * 128 + BTS_MAX_TAP * 8;
-    static DynLdsCache set2, set4;
+    static DynLdsCache set2, set4, set2i;
+    if (variant == 3) {
+        if (ensure_dyn_lds((const void*)conv_igemm_pp<2, true>, lds, set2i) != BTS_OK) return BTS_ERR_LAUNCH;
+        hipLaunchKernelGGL((conv_igemm_pp<2, true>), grid, dim3(512), (size_t)lds, st, k);
+        if (hipGetLastError() != hipSuccess) return BTS_ERR_LAUNCH;
+        return BTS_OK;
+    }
     if (variant == 4) {
-        if (ensure_dyn_lds((const void*)conv_igemm_pp<4>, lds, set4) != BTS_OK) return BTS_ERR_LAUNCH;
-        hipLaunchKernelGGL(conv_igemm_pp<4>, grid, dim3(512), (size_t)lds, st, k);
+        if (ensure_dyn_lds((const void*)conv_igemm_pp<4, false>, lds, set4) != BTS_OK) return BTS_ERR_LAUNCH;
+        hipLaunchKernelGGL((conv_igemm_pp<4, false>), grid, dim3(512), (size_t)lds, st, k);
     } else {
-        if (ensure_dyn_lds((const void*)conv_igemm_pp<2>, lds, set2) != BTS_OK) return BTS_ERR_LAUNCH;
-        hipLaunchKernelGGL(conv_igemm_pp<2>, grid, dim3(512), (size_t)lds, st, k);
+        if (ensure_dyn_lds((const void*)conv_igemm_pp<2, false>, lds, set2) != BTS_OK) return BTS_ERR_LAUNCH;
+        hipLaunchKernelGGL((conv_igemm_pp<2, false>), grid, dim3(512), (size_t)lds, st, k);
     }
     if (hipGetLastError() != hipSuccess) return BTS_ERR_LAUNCH;
     return BTS_OK;

@@ -119,6 +119,23 @@ class GradAllReducer:
                 flat.mul_(1.0 / self.world)
         self._works = []
 
+    def reduce_all(self):
+        """Exchange every bucket NOW, on the current stream, and turn the sums into means.  For steps whose backward ran
+        with the hooks deferred (``no_sync()``) -- in particular a forward+backward replayed from a captured hipGraph, where
+        no Python hook runs at all: graph(fwd+bwd) -> reduce_all() -> graph(optimizer).  The exchange is then not
+        overlapped with the backward pass (3 messages, 188 MB for DenseNet161-BTS), which is the price of replaying ~2000
+        kernel launches from one graph instead of issuing them from Python."""
+        self._reset()
+        for bi in range(len(self.buckets)):
+            self._pending[bi] = 0
+            self._launch(bi)
+        for bi, w in self._works:
+            w.wait()
+        if self.world > 1:
+            for flat, _ in self.buckets:
+                flat.mul_(1.0 / self.world)
+        self._works = []
+
     def remove(self):
         for h in self._hooks:
             h.remove()

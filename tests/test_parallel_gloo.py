@@ -91,6 +91,23 @@ def _worker(rank, world, port, bucket_bytes, q):
         red.zero_grad()
         net(x).pow(2).mean().backward()
         red.finish()
+        # deferred form (bench.py N>1 with hipGraphs: the backward is replayed, no hook runs): whole backward under
+        # no_sync(), then reduce_all() exchanges every bucket at once -- same means as the hook-driven exchange
+        red.zero_grad()
+        with red.no_sync():
+            net(x).pow(2).mean().backward()
+        red.reduce_all()
+        ref.zero_grad()
+        ref(x).pow(2).mean().backward()
+        for (n, p), (_, pr) in zip(net.named_parameters(), ref.named_parameters()):
+            if p.requires_grad:
+                g = pr.grad.clone() if pr.grad is not None else torch.zeros_like(pr)
+                dist.all_reduce(g)
+                g /= world
+                assert torch.allclose(p.grad, g, rtol=1e-6, atol=1e-7), ("reduce_all", n)
+        red.zero_grad()
+        net(x).pow(2).mean().backward()
+        red.finish()
         # every rank ends with identical gradients (what the optimizer sees)
         flat = torch.cat([b[0] for b in red.buckets])
         gathered = [torch.zeros_like(flat) for _ in range(world)]

@@ -1,21 +1,23 @@
-mkdir -p gpurun_out/r02e
+mkdir -p gpurun_out/r02g
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r02e
-for v in x y s; do
-  BTS_CONV_BIG=$v timeout 300 python -m pytest tests/test_gpu_1_kernels.py -q -x -k "conv_fwd_dgrad_wgrad or conv_epilogues" > $O/pytest_conv_$v.log 2>&1
-done
-for v in a x y; do
-  BTS_CONV_BIG=$v timeout 200 python tools/kernel_probe.py --set mid --iters 10 > $O/mid_$v.jsonl 2> $O/mid_$v.err
-done
-BTS_CONV_BIG=x BTS_PARITY_DUMP=$O/parity_x timeout 300 python -m pytest tests/test_gpu_3_fullsize.py -q -k "parity and bf16" > $O/pytest_parity_x.log 2>&1
-BTS_CONV_BIG=y BTS_PARITY_DUMP=$O/parity_y timeout 300 python -m pytest tests/test_gpu_3_fullsize.py -q -k "parity and bf16" > $O/pytest_parity_y.log 2>&1
-BTS_CONV_BIG=x timeout 300 python -m pytest tests/test_gpu_4_model.py -q -k "determinism" > $O/pytest_det_x.log 2>&1
-BTS_CONV_BIG=y timeout 300 python -m pytest tests/test_gpu_4_model.py -q -k "determinism" > $O/pytest_det_y.log 2>&1
-timeout 300 python -m pytest tests/test_gpu_1_kernels.py -q -x > $O/pytest_k1.log 2>&1
-for v in x y s; do tail -2 $O/pytest_conv_$v.log; done
-for v in a x y; do echo $v; python - <<PY
-import json
-print([ (json.loads(l)["case"], json.loads(l)["tflops"]) for l in open("$O/mid_$v.jsonl") if l.startswith("{")])
-PY
-done
-tail -2 $O/pytest_parity_x.log; tail -2 $O/pytest_parity_y.log; tail -2 $O/pytest_det_x.log; tail -2 $O/pytest_det_y.log; tail -2 $O/pytest_k1.log
+O=$GRAFT_REPO_ROOT/gpurun_out/r02g
+B="--no-cpu-baseline --no-kernel-events --steps 20 --warmup 5"
+timeout 200 python bench.py $B --graph 0 > $O/bench_eager.json 2> $O/bench_eager.err
+timeout 200 python bench.py $B --force-dist 1 > $O/bench_split.json 2> $O/bench_split.err
+timeout 200 python bench.py $B --force-dist 1 --reducer ddp > $O/bench_ddp1.json 2> $O/bench_ddp1.err
+timeout 200 python bench.py $B --force-dist 1 --reducer bts > $O/bench_bts1.json 2> $O/bench_bts1.err
+timeout 200 python -m pytest tests/test_gpu_4_model.py -q -k "rccl" > $O/pytest_rccl.log 2>&1
+P="--graph 0 --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events"
+cd /tmp
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o b -- python $GRAFT_REPO_ROOT/bench.py $P > $O/pmc_f.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o b -- python $GRAFT_REPO_ROOT/bench.py $P > $O/pmc_w.log 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/pmc_traffic.py $O/pmc_f/b_counter_collection.csv $O/pmc_w/b_counter_collection.csv $O/pmc_traffic.json > $O/pmc_traffic.log 2>&1
+rm -f $O/pmc_f/b_kernel_trace.csv $O/pmc_w/b_kernel_trace.csv
+for f in eager split ddp1 bts1; do head -c 900 $O/bench_$f.json | python -c "
+import sys,json
+try:
+    d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['config']['launch'], d['config']['final_loss'])
+except Exception as e: print('$f ERR', e)
+"; tail -2 $O/bench_$f.err; done
+tail -3 $O/pytest_rccl.log; cat $O/pmc_traffic.log; du -sh $O

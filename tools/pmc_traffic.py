@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""HBM-side traffic per launch of the bench's kernel families -> profiles/pmc_traffic.json (read by bench.py's
+`roofline.traffic`).
+
+Input: the two rocprofv3 counter-collection CSVs of the SAME bench command, one pass per counter as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2):
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out/f -o b -- python bench.py --graph 0 --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out/w -o b -- python bench.py --graph 0 --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events
+    python tools/pmc_traffic.py out/f/b_counter_collection.csv out/w/b_counter_collection.csv profiles/pmc_traffic.json
+
+Units and corrections: both counters are reported in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide
+coalesced reads at 64 B, so it is doubled (same guide, HBM section); WRITE_SIZE is taken as is (uncalibrated there).
+Infinity-Cache hits are counted by both, so this is fabric-side traffic, an upper bound of what reaches HBM.
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def family(name):
+    """Kernel symbol -> the family label bench.py uses (bts_amd/conv.py::_fwd_kernel / _wgrad_kernel, profiler labels)."""
+    n = re.sub(r"\(anonymous namespace\)::|bts_conv::|^void ", "", name)
+    n = re.sub(r"\(.*$", "", n)
+    m = re.match(r"conv_igemm_dma<BF16, (\d), (\d), (\d), (\d)", n)
+    if m:
+        wr, wc, tm, tn = map(int, m.groups())
+        return "conv_igemm_dma<bf16,%dx%d>" % (wr * tm * 32, wc * tn * 32)
+    if n.startswith("conv_wgrad_tr"):
+        return "conv_wgrad_tr<bf16,128x128>"
+    if n.startswith("conv_halo<BF16"):
+        return "conv_halo<bf16>"
+    if n.startswith("conv_wgrad_halo_up"):
+        return "conv_wgrad_halo_up<bf16>"
+    if n.startswith("conv_wgrad_halo"):
+        return "conv_wgrad_halo<bf16>"
+    if n.startswith("lpg_chain_") or n.startswith("lpg_head_"):
+        return "lpg_head*"
+    return None
+
+
+def load(path, counter):
+    per = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") != counter:
+            continue
+        f = family(r["Kernel_Name"])
+        if f:
+            per[f].append(float(r["Counter_Value"]))
+    return per
+
+
+def main():
+    fpath, wpath, out = sys.argv[1:4]
+    fetch, write = load(fpath, "FETCH_SIZE"), load(wpath, "WRITE_SIZE")
+    table = {}
+    for fam in sorted(set(fetch) & set(write)):
+        nf, nw = len(fetch[fam]), len(write[fam])
+        rd = 2.0 * 1024.0 * sum(fetch[fam]) / nf
+        wr = 1024.0 * sum(write[fam]) / nw
+        table[fam] = {"bytes_per_launch": round(rd + wr), "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+                      "launches_fetch_pass": nf, "launches_write_pass": nw,
+                      "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --graph 0; FETCH_SIZE x2 "
+                                "(gfx950 tallies 128-B requests at 64 B), KiB -> bytes; fabric-side, Infinity-Cache hits included"}
+    with open(out, "w") as f:
+        json.dump(table, f, indent=1)
+    for k, v in table.items():
+        print("%-32s %8.1f MB/launch (read %.1f, write %.1f) over %d launches" % (k, v["bytes_per_launch"] / 1e6, v["read_bytes_per_launch"] / 1e6,
+                                                                               v["write_bytes_per_launch"] / 1e6, v["launches_fetch_pass"]))
+
+
+if __name__ == "__main__":
+    main()
