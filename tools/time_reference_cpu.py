@@ -3,7 +3,7 @@ silog_loss, imported through oracle/ref_loader.py) and the oracle port on the SA
 input -- one train step (fwd + loss + bwd), f32.  BASELINE.md section 2 protocol: 2 warm-up + >= 5 timed, median.
 Runs only where /root/reference exists (the build container); writes one JSON object.
 
-    python tools/time_reference_cpu.py --height 176 --width 608 --out profiles/r02_cpu_reference_vs_port.json
+    python tools/time_reference_cpu.py --height 160 --width 608 --out profiles/r02_cpu_reference_vs_port.json
 """
 import argparse
 import json
@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--encoder", default="densenet161_bts")
-    ap.add_argument("--height", type=int, default=176)
+    ap.add_argument("--height", type=int, default=160)
     ap.add_argument("--width", type=int, default=608)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=2)
