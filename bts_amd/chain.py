@@ -18,7 +18,7 @@ from .ops import pix_stride
 
 _PERM = [0, 1, 2, 3, 8, 9, 10, 11]
 SUPPORTED = {(128, 1, 8), (128, 0, 4), (64, 0, 2), (32, 0, 1), (64, 1, 8), (64, 0, 4), (32, 0, 2), (16, 0, 1),
-             (32, 1, 8), (32, 0, 4), (16, 0, 2), (64, 0, 8), (32, 0, 8), (16, 0, 8)}
+             (32, 1, 8), (32, 0, 4), (16, 0, 2), (64, 0, 8), (32, 0, 8), (16, 0, 8), (128, 0, 8)}
 
 
 def supported(c0, same_first, k):
@@ -95,7 +95,7 @@ def pack_chain(weights, dtype):
     return torch.cat(parts).contiguous()
 
 
-BWD_SUPPORTED = {(64, 2), (32, 1), (64, 4), (32, 2), (16, 1), (32, 4), (16, 2), (64, 8), (32, 8), (16, 8)}
+BWD_SUPPORTED = {(64, 2), (32, 1), (64, 4), (32, 2), (16, 1), (32, 4), (16, 2), (64, 8), (32, 8), (16, 8), (128, 4), (128, 8)}
 
 
 def bwd_supported(c0, same_first, k, dtype):

@@ -264,6 +264,7 @@ int dispatch_chain(const ChainK& k, int c0, int same_first, int kup, hipStream_t
     CASE(64, 1, 8); CASE(64, 0, 4); CASE(32, 0, 2); CASE(16, 0, 1);        // bts_size 256
     CASE(32, 1, 8); CASE(32, 0, 4); CASE(16, 0, 2);                        // bts_size 128 (reduc1x1 there is 8->1: unfused)
     CASE(64, 0, 8); CASE(32, 0, 8); CASE(16, 0, 8);                        // halving tails of reduc8x8 (training: wide prefix layer-wise)
+    CASE(128, 0, 8);                                                       // reduc8x8 behind its 128 -> 128 layer (training)
 #undef CASE
     return BTS_ERR_UNSUPPORTED;
 }
@@ -487,8 +488,12 @@ struct BwdLayer {
     }
 };
 
+// C0 = 128 (reduc4x4 whole, reduc8x8 behind its 128 -> 128 layer; bts.py:171, 178): the 128 -> 64 layer alone owns 8 of the 13
+// weight-gradient tiles (208 accumulator registers per wave), so that instantiation runs ONE wave per SIMD with the whole
+// 512-entry register file (the LDS footprint -- 48 KiB of fragments + 60 KiB of transpose scratch -- allows one workgroup per
+// CU anyway); the narrower chains keep two.
 template <int C0, int KUP>
-__global__ __launch_bounds__(256, 2) void lpg_chain_bwd_kernel(const ChainBwdK a) {
+__global__ __launch_bounds__(256, (C0 >= 128 ? 1 : 2)) void lpg_chain_bwd_kernel(const ChainBwdK a) {
     constexpr int NOUT = KUP == 1 ? 1 : 3;
     constexpr int NTOT = bwd_dw_tiles<C0, NOUT>();
     constexpr int SROWS = bwd_scr_rows<C0, NOUT>();
@@ -616,7 +621,8 @@ extern "C" int bts_lpg_chain_bwd(const void* x, int dtype, int x_stride, int c0,
     CASE(64, 2); CASE(32, 1);               // bts_size 512: reduc2x2, reduc1x1 (bts.py:186, 190)
     CASE(64, 4); CASE(32, 2); CASE(16, 1);  // bts_size 256
     CASE(32, 4); CASE(16, 2);               // bts_size 128
-    CASE(64, 8); CASE(32, 8); CASE(16, 8);  // halving tails of reduc8x8 behind its layer-wise 128 -> 128 -> 64 prefix
+    CASE(64, 8); CASE(32, 8); CASE(16, 8);  // halving tails of reduc8x8 behind a layer-wise prefix
+    CASE(128, 4); CASE(128, 8);             // bts_size 512: reduc4x4 whole; reduc8x8 behind its (layer-wise) 128 -> 128 layer
 #undef CASE
     return BTS_ERR_UNSUPPORTED;
 }

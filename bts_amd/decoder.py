@@ -470,7 +470,7 @@ class DecoderRun:
             if g is not None:
                 # the LPG maps also receive gradient through conv1/conv3/conv2: own the buffer
                 o.g = g.reshape(o.t.shape).to(torch.float32).clone(memory_format=torch.contiguous_format)
-        dev = self.outs[0].t.device
+        dev = next(iter(self.packs.fwd.values())).device
         self.packs.pack_dgrad()
         self.dwp_arena = torch.zeros(self.packs.dwp_total, dtype=torch.float32, device=dev)     # one memset for every layer
         for fn in reversed(self.tape):

@@ -20,8 +20,11 @@ import operator
 import torch
 import torch.nn as nn
 
+import math
+
 from . import ops
-from ._lib import BtsAmdError, require_gpu
+from ._lib import ACT_ELU, ACT_NONE, BtsAmdError, require_gpu
+from .conv import ConvLayer
 from .decoder import DecoderPlan, DecoderRun, reduction_specs
 
 __all__ = ["BtsModel", "bts", "encoder", "silog_loss", "weights_init_xavier", "bn_init_as_tf",
@@ -87,8 +90,61 @@ class silog_loss(nn.Module):
 # building blocks: parameter containers with the reference's names; standalone forward() of the
 # LPG layer goes through the LPG op of the C ABI
 # ---------------------------------------------------------------------------------------------
+class _BlockPlan:
+    """Duck-typed DecoderPlan of ONE building block (what DecoderRun / PackSet need: layers, reduc, caches)."""
+
+    def __init__(self, layers, reduc=None):
+        self.layers, self.reduc = layers, reduc or {}
+        self.chain_cache, self.pack_cache = {}, {}
+
+
+class _BlockFn(torch.autograd.Function):
+    """Standalone forward / backward of a building block on the decoder's executor (same kernels, same tape): the
+    reference exposes atrous_conv / upconv / reduction_1x1 as working modules (bts.py:51-122)."""
+
+    @staticmethod
+    def forward(ctx, mod, names, record, x, *params):
+        require_gpu(x)
+        P = dict(zip(names, (p.detach() for p in params)))
+        for k, b in mod.named_buffers():
+            P[k] = b
+        bn_training = {k: m.training for k, m in mod.named_modules() if isinstance(m, nn.BatchNorm2d)}
+        run = DecoderRun(mod._plan, P, bn_training, float(getattr(mod, "max_depth", 1.0)), "block", mod.compute_dtype, record)
+        run.packs.pack_forward()
+        y = mod._schedule(run, run.feature(x))
+        run.outs = []
+        ctx.run, ctx.y, ctx.names = run, y, names
+        if y.t.dim() == 3:                                       # single-channel f32 map (reduction_1x1 final)
+            return y.t.unsqueeze(1).clone()
+        return ops.nhwc_to_nchw(y.t, mod._cout, out_dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, gy):
+        run, y = ctx.run, ctx.y
+        if run is None:
+            raise BtsAmdError("one backward tape per forward pass: run the block's forward again")
+        if y.t.dim() == 3:
+            y.g = gy.reshape(y.t.shape).to(torch.float32).contiguous().clone()
+        else:
+            y.g = ops.nchw_to_nhwc(gy.to(torch.float32).contiguous(), y.t.dtype, c_pad=y.t.shape[3])
+        gfeats, grads = run.backward([])
+        ctx.run = None
+        return (None, None, None, gfeats[0]) + tuple(grads.get(n) for n in ctx.names)
+
+
+def _run_block(mod, x):
+    if x.shape[1] % 8:
+        raise BtsAmdError("standalone %s: input channels must be a multiple of 8 (got %d)" % (type(mod).__name__, x.shape[1]))
+    names = tuple(n for n, _ in mod.named_parameters())
+    params = tuple(p for _, p in mod.named_parameters())
+    record = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    src = x if x.dtype in (torch.float32, torch.bfloat16) else x.float()
+    return _BlockFn.apply(mod, names, record, src.contiguous(), *params)
+
+
 class atrous_conv(nn.Sequential):
-    """bts.py:51-66 (container).  Child names: atrous_conv.{first_bn, aconv_sequence.{0..4}}."""
+    """bts.py:51-66.  Child names: atrous_conv.{first_bn, aconv_sequence.{0..4}}.  Inside ``bts`` the fused decoder
+    executes it; called on its own it runs the same kernels through ``_BlockFn``."""
 
     def __init__(self, in_channels, out_channels, dilation, apply_bn_first=True):
         super().__init__()
@@ -104,8 +160,21 @@ class atrous_conv(nn.Sequential):
             nn.Conv2d(out_channels * 2, out_channels, kernel_size=3, stride=1, padding=(dilation, dilation),
                       dilation=dilation, bias=False)))
 
+        self._dil, self._first, self._cout = dilation, apply_bn_first, out_channels
+        p = "atrous_conv.aconv_sequence"
+        self._plan = _BlockPlan({p + ".1": ConvLayer(p + ".1", out_channels * 2, [in_channels], 1),
+                                 p + ".4": ConvLayer(p + ".4", out_channels, [out_channels * 2], 9, dilation)})
+        self.compute_dtype = torch.float32
+
+    def _schedule(self, run, a):
+        p = "atrous_conv.aconv_sequence"
+        n = run.bn(a, "atrous_conv.first_bn", 1.1e-5, relu=True) if self._first else run.relu(a)      # bts.py:54-57
+        c = run.conv(p + ".1", [n], ACT_NONE)
+        c = run.bn(c, p + ".2", 1e-5, relu=True)                                                    # bts.py:60-61
+        return run.conv(p + ".4", [c], ACT_NONE)
+
     def forward(self, x):
-        raise BtsAmdError("atrous_conv is executed by the fused decoder (bts.forward); it has no standalone path")
+        return _run_block(self, x)
 
 
 class upconv(nn.Module):
@@ -117,8 +186,17 @@ class upconv(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=False)
         self.ratio = ratio
 
+        if ratio != 2:
+            raise BtsAmdError("upconv: only ratio 2 (the only one bts.py uses) has a kernel")
+        self._cout = out_channels
+        self._plan = _BlockPlan({"conv": ConvLayer("conv", out_channels, [in_channels], 9, 1, True)})
+        self.compute_dtype = torch.float32
+
+    def _schedule(self, run, a):
+        return run.conv("conv", [a], ACT_ELU)               # nearest x2 folded into 4 sub-pixel phases (bts.py:76-80)
+
     def forward(self, x):
-        raise BtsAmdError("upconv is executed by the fused decoder (bts.forward); it has no standalone path")
+        return _run_block(self, x)
 
 
 class reduction_1x1(nn.Sequential):
@@ -139,8 +217,32 @@ class reduction_1x1(nn.Sequential):
             else:
                 self.reduc.add_module(child, torch.nn.Sequential(conv, nn.ELU()))
 
+        layers, keys = {}, []
+        for child, cin, cout in reduction_specs(num_in_filters, num_out_filters, is_final):
+            key = "reduc.%s" % (child + (".0" if child != "plane_params" else ""))
+            layers[key] = ConvLayer(key, cout, [cin], 1)
+            keys.append(key)
+        self._chain = "reduc1x1" if is_final else "reduc"           # DecoderRun.chain ends with the sigmoid map for reduc1x1
+        self._plan = _BlockPlan(layers, {self._chain: keys})
+        self._cout = 1 if is_final else 3
+        self.compute_dtype = torch.float32
+
+    def _schedule(self, run, a):
+        return run.chain(self._chain, a)
+
     def forward(self, net):
-        raise BtsAmdError("reduction_1x1 is executed by the fused decoder (bts.forward); it has no standalone path")
+        raw = _run_block(self, net)                                  # 1x1 + ELU chain on the HIP kernels (bts.py:110)
+        if self.is_final:
+            return raw                                               # sigmoid map (bts.py:93-96)
+        # plane parameters -> (n1, n2, n3, n4), bts.py:112-120: a dozen elementwise ops on a [B,3,h,w] tensor; inside the
+        # decoder this tail lives in the fused LPG head kernels, the standalone module keeps it as (differentiable) torch ops
+        theta = torch.sigmoid(raw[:, 0]) * math.pi / 3
+        phi = torch.sigmoid(raw[:, 1]) * math.pi * 2
+        dist = torch.sigmoid(raw[:, 2]) * self.max_depth
+        n1 = torch.mul(torch.sin(theta), torch.cos(phi)).unsqueeze(1)
+        n2 = torch.mul(torch.sin(theta), torch.sin(phi)).unsqueeze(1)
+        n3 = torch.cos(theta).unsqueeze(1)
+        return torch.cat([n1, n2, n3, dist.unsqueeze(1)], dim=1)
 
 
 class _LpgFn(torch.autograd.Function):

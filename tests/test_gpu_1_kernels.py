@@ -278,7 +278,7 @@ def test_layout_roundtrip_and_pack_maps():
         assert torch.equal(gm[s], g[..., s])
 
 
-@pytest.mark.parametrize("c0,k", [(64, 2), (32, 1), (16, 2), (64, 4), (16, 1), (32, 4), (64, 8), (16, 8)])
+@pytest.mark.parametrize("c0,k", [(64, 2), (32, 1), (16, 2), (64, 4), (16, 1), (32, 4), (64, 8), (16, 8), (128, 4), (128, 8)])
 @pytest.mark.parametrize("acc", [False, True])
 def test_lpg_chain_bwd_vs_autograd(c0, k, acc):
     """Fused recompute backward of a narrow reduction chain + head (csrc/lpg_chain.hip) against PyTorch autograd of
@@ -308,7 +308,10 @@ def test_lpg_chain_bwd_vs_autograd(c0, k, acc):
     frags, frags_t = chain.pack_chain(wd, torch.bfloat16), chain.pack_chain_t(wd, torch.bfloat16)
     xd = x.to(DEV)
     out = chain.chain_fwd(xd, frags, c0, False, k, md)
-    assert rel(out, ref.reshape(out.shape)) < 2e-2
+    wide = c0 >= 128            # one more bf16-rounded layer with a 128-wide contraction: ~1.5x the rounding noise
+    e_fwd = rel(out, ref.reshape(out.shape))
+    print("chain c0=%d k=%d fwd max-rel %.3e" % (c0, k, e_fwd))
+    assert e_fwd < (5e-2 if wide else 2e-2)
     gx0 = torch.randn(B, h, w, c0, generator=gen).bfloat16()
     gx = gx0.to(DEV) if acc else torch.full((B, h, w, c0), float("nan"), dtype=torch.bfloat16, device=DEV)
     gws = [torch.zeros(dims[i + 1], max(dims[i], 8), device=DEV) for i in range(len(dims) - 1)]
@@ -318,10 +321,13 @@ def test_lpg_chain_bwd_vs_autograd(c0, k, acc):
         return ((a_ - b_).norm() / b_.norm()).item()
     want = xr.grad.permute(0, 2, 3, 1) + (gx0.float() if acc else 0.0)
     # bf16 rounding of dz / activations at every layer: ~1 % per element, a few % on the ill-conditioned planes
-    assert rel_l2(gx.float(), want) < 2e-2 and rel(gx.float(), want) < 8e-2
+    l2b, mxb, mxw = (3e-2, 0.12, 8e-2) if wide else (2e-2, 8e-2, 5e-2)
+    print("chain c0=%d k=%d dx L2 %.3e max %.3e" % (c0, k, rel_l2(gx.float(), want), rel(gx.float(), want)))
+    assert rel_l2(gx.float(), want) < l2b and rel(gx.float(), want) < mxb
     for g, wi in zip(gws, wr):
         ref_g = wi.grad.reshape(wi.shape[0], wi.shape[1])
-        assert rel_l2(g[:, :wi.shape[1]], ref_g) < 2e-2 and rel(g[:, :wi.shape[1]], ref_g) < 5e-2
+        print("   dW %s L2 %.3e max %.3e" % (tuple(wi.shape[:2]), rel_l2(g[:, :wi.shape[1]], ref_g), rel(g[:, :wi.shape[1]], ref_g)))
+        assert rel_l2(g[:, :wi.shape[1]], ref_g) < l2b and rel(g[:, :wi.shape[1]], ref_g) < mxw
         assert g[:, wi.shape[1]:].abs().max().item() == 0.0 if g.shape[1] > wi.shape[1] else True
 
 

@@ -198,3 +198,57 @@ def test_decoder_ragged_shapes_vs_oracle(B, H, W):
             outs2 = dec([f.to(DEV) for f in feats], focal.to(DEV))      # fused no-grad heads
         for o, r in zip(outs2, ref):
             assert rel(o, r) < 1e-4
+
+
+@pytest.mark.parametrize("block", ["upconv", "atrous_first_bn", "atrous_plain", "reduction", "reduction_final"])
+def test_standalone_blocks_vs_oracle(block):
+    """The reference exposes its building blocks as working modules (bts.py:51-122); here they run the decoder's kernels on
+    their own: output, input gradient, every parameter gradient and the BN running statistics vs the oracle's functions."""
+    from bts_amd.model import atrous_conv, reduction_1x1, upconv
+    gen = torch.Generator().manual_seed(11)
+    N, H, W = 2, 12, 20
+    if block == "upconv":
+        mod = upconv(16, 24)
+        x = torch.randn(N, 16, H, W, generator=gen)
+    elif block.startswith("atrous"):
+        mod = atrous_conv(32, 16, 6, apply_bn_first=block == "atrous_first_bn")
+        x = torch.randn(N, 32, H, W, generator=gen)
+    else:
+        mod = reduction_1x1(64, 32, 10.0, is_final=block == "reduction_final") if block == "reduction" else \
+            reduction_1x1(32, 16, 10.0, is_final=True)
+        x = torch.randn(N, mod.reduc[0][0].in_channels, H, W, generator=gen)
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * (0.3 if p.dim() > 1 else 1.0) + (1.0 if n.endswith("bn.weight") or ".2.weight" in n else 0.0))
+        for n, b in mod.named_buffers():
+            if "running_var" in n:
+                b.copy_(torch.rand(b.shape, generator=gen) + 0.5)
+            elif "running_mean" in n:
+                b.copy_(torch.randn(b.shape, generator=gen) * 0.1)
+    P = {"m." + k: v.detach().clone() for k, v in mod.state_dict().items()}
+    Pr = {k: (v.requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    st = O.BNState(True)
+    if block == "upconv":
+        ref = O._upconv(xr, Pr["m.conv.weight"])
+    elif block.startswith("atrous"):
+        ref = O._atrous(xr, Pr, "m", 6, st, block == "atrous_first_bn")
+    else:
+        ref = O.reduction_chain(xr, Pr, "m", 10.0, block == "reduction_final")
+    gy = torch.randn(ref.shape, generator=gen)
+    ref.backward(gy)
+    mod.to(DEV).train()
+    xd = x.to(DEV).requires_grad_(True)
+    out = mod(xd)
+    assert out.shape == ref.shape
+    assert rel(out, ref) < 1e-4
+    out.backward(gy.to(DEV))
+    assert rel(xd.grad, xr.grad) < 1e-4
+    for n, p in mod.named_parameters():
+        assert p.grad is not None, n
+        assert rel(p.grad, Pr["m." + n].grad) < 1e-4, n
+    for k, v in st.updates.items():
+        assert rel(mod.state_dict()[k[2:]], v) < 1e-4, k
+    with torch.no_grad():                                   # the no-grad path keeps no tape
+        out2 = mod.eval()(x.to(DEV))
+    assert out2.shape == ref.shape and torch.isfinite(out2).all()
