@@ -449,7 +449,8 @@ def main():
     if prof is not None:
         profiler.disable()
         roof = prof.summary(PEAK[args.dtype], HBM_PEAK_GBS, args.steps)
-        attach_traffic(roof)
+        if (args.encoder, args.height, args.width, args.batch, args.dtype) == ("densenet161_bts", 352, 1216, 8, "bf16"):
+            attach_traffic(roof)        # the PMC passes were taken on this configuration only
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         out = {
@@ -458,8 +459,9 @@ def main():
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "%s train step (fwd+silog+bwd+AdamW), %dx%d, %d img/GPU, kitti focal scaling" %
-                       (args.encoder, args.height, args.width, args.batch),
+            "config": {"workload": "%s train step (fwd+silog+bwd+AdamW), %dx%d, %d img/GPU, %s" %
+                       (args.encoder, args.height, args.width, args.batch,
+                        "kitti focal scaling" if args.dataset == "kitti" else "nyu (no focal scaling)"),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "grad_exchange": ("none" if not multi else ("torch DDP over %s" % args.backend if reducer is None else "bts GradAllReducer over %s" % args.backend)),
                        "encoder": "stock PyTorch-ROCm (%s autocast)" % args.dtype, "decoder": "HIP kernels via libbts_amd.so", "launch": graph_note, "optimizer": "bts_adamw_step (fused HIP)" if own_opt else "torch.optim.AdamW(fused)",
                        "final_loss": round(final_loss, 5)},

@@ -1,14 +1,20 @@
-mkdir -p gpurun_out/r02h
+mkdir -p gpurun_out/r02i
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r02h
-timeout 300 python -m pytest tests/test_gpu_1_kernels.py -q -x -k "chain" > $O/pytest_chain.log 2>&1
-timeout 300 python -m pytest tests/test_gpu_2_decoder.py -q > $O/pytest_dec.log 2>&1
-BTS_PARITY_DUMP=$O/parity timeout 300 python -m pytest tests/test_gpu_3_fullsize.py -q -k "parity and bf16" > $O/pytest_parity.log 2>&1
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
-tail -3 $O/pytest_chain.log; tail -15 $O/pytest_dec.log; tail -3 $O/pytest_parity.log
-python - <<PY
+O=$GRAFT_REPO_ROOT/gpurun_out/r02i
+timeout 900 python -m pytest tests -m gpu -x -q --durations=6 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
+timeout 400 python bench.py --steps 20 --warmup 5 > $O/bench_bf16.json 2> $O/bench_bf16.err
+timeout 300 python bench.py --dtype f32 --no-cpu-baseline > $O/bench_f32.json 2> $O/bench_f32.err
+timeout 300 python bench.py --height 416 --width 544 --batch 16 --dataset nyu --no-cpu-baseline > $O/bench_c2.json 2> $O/bench_c2.err
+timeout 300 python bench.py --encoder resnext101_bts --dtype f32 --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_c4.json 2> $O/bench_c4.err
+timeout 300 python bench.py --mode infer > $O/bench_infer.json 2> $O/bench_infer.err
+tail -6 $O/pytest_gpu.log; tail -2 $O/smoke.log
+for f in bf16 f32 c2 c4 infer; do python - <<PY
 import json
-for l in open("$O/bench.json"):
-    if l.startswith("{"):
-        d=json.loads(l); print(d["value"], d["ms_per_step"]); print(d["roofline_lpg"]); print(d["kernel_time_ms_per_step"]); print(d["hip_kernels_ms_per_step"])
+try:
+    for l in open("$O/bench_$f.json"):
+        if l.startswith("{"):
+            d=json.loads(l); print("$f", d["metric"][:50], d["value"], d.get("ms_per_step"), d.get("roofline",{}).get("frac"), d.get("cpu_baseline",{}) and d["cpu_baseline"].get("value"))
+except Exception as e: print("$f ERR", e)
 PY
+done
