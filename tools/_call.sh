@@ -1,20 +1,16 @@
-mkdir -p gpurun_out/r02i
+mkdir -p gpurun_out/r02j
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r02i
-timeout 900 python -m pytest tests -m gpu -x -q --durations=6 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
-timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
-timeout 400 python bench.py --steps 20 --warmup 5 > $O/bench_bf16.json 2> $O/bench_bf16.err
-timeout 300 python bench.py --dtype f32 --no-cpu-baseline > $O/bench_f32.json 2> $O/bench_f32.err
-timeout 300 python bench.py --height 416 --width 544 --batch 16 --dataset nyu --no-cpu-baseline > $O/bench_c2.json 2> $O/bench_c2.err
-timeout 300 python bench.py --encoder resnext101_bts --dtype f32 --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_c4.json 2> $O/bench_c4.err
-timeout 300 python bench.py --mode infer > $O/bench_infer.json 2> $O/bench_infer.err
-tail -6 $O/pytest_gpu.log; tail -2 $O/smoke.log
-for f in bf16 f32 c2 c4 infer; do python - <<PY
-import json
-try:
-    for l in open("$O/bench_$f.json"):
-        if l.startswith("{"):
-            d=json.loads(l); print("$f", d["metric"][:50], d["value"], d.get("ms_per_step"), d.get("roofline",{}).get("frac"), d.get("cpu_baseline",{}) and d["cpu_baseline"].get("value"))
-except Exception as e: print("$f ERR", e)
-PY
-done
+O=$GRAFT_REPO_ROOT/gpurun_out/r02j
+timeout 200 python -m pytest tests/test_gpu_1_kernels.py -q -x -k "chain" > $O/pytest_chain.log 2>&1
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 10 > $O/stats.log 2>&1
+P="--graph 0 --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events"
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o b -- python $GRAFT_REPO_ROOT/bench.py $P > $O/pmc_f.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o b -- python $GRAFT_REPO_ROOT/bench.py $P > $O/pmc_w.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc_sq_fwd -o m -- python $GRAFT_REPO_ROOT/tools/kernel_probe.py --set fwd --iters 2 > $O/pmc_sq_fwd.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc_sq_wgrad -o m -- python $GRAFT_REPO_ROOT/tools/kernel_probe.py --set wgrad --iters 2 > $O/pmc_sq_wgrad.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc_inst_fwd -o m -- python $GRAFT_REPO_ROOT/tools/kernel_probe.py --set fwd --iters 2 > $O/pmc_inst_fwd.log 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/pmc_traffic.py $O/pmc_f/b_counter_collection.csv $O/pmc_w/b_counter_collection.csv $O/pmc_traffic.json > $O/pmc_traffic.log 2>&1
+find $O -name '*kernel_trace.csv' -size +3M -delete
+tail -3 $O/pytest_chain.log; ls $O/stats; cat $O/pmc_traffic.log; du -sh $O
