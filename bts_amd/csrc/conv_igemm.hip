@@ -16,6 +16,8 @@
 // torch.cat / F.interpolate(nearest) around them; see include/bts_amd.h for the descriptor.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "conv_common.h"
 
@@ -493,6 +495,52 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
     const int nchunks = (a.KV + 7) >> 3;
     const int frow = lane & 31, fk = lane >> 5;
 
+    // Tile-invariant addressing, computed once (r2: SQ counters showed 18 VALU + 11 SALU instructions per MFMA in this kernel,
+    // most of them re-deriving these per tile / per tap):
+    //  * B fragments: patch row of this lane under tap t, prow = (wave+1+dy)*PW + frow+1+dx -> byte offset and swizzled slot of
+    //    every k-step (the XOR swizzle depends on the row, hence on the tap);
+    //  * A fragments: weight row t*32 + frow -> the swizzle term (row>>1)&7 does not depend on t (t*32 is a multiple of 16), so
+    //    one offset per k-step plus t*4096 as an immediate;
+    //  * DMA rows of the patch: (pyy, pxx) of the six rows this thread fetches per tile.
+    constexpr bool FULLTAB = NT <= 9;             // 16-tap (sub-pixel) variants: a 64-entry table would spill; they re-derive the row
+    int pB[FULLTAB ? NT : 1][4];
+    if constexpr (FULLTAB) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int dy, dx, ioy, iox;
+            decode_tap(a.taps[t], dy, dx, ioy, iox);
+            const int prow = (wave + 1 + dy) * PW + (frow + 1 + dx);
+            const int pswz = (prow >> 1) & 7;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) pB[t][s] = prow * 128 + (((2 * s + fk) ^ pswz) << 4);
+        }
+    }
+    auto pb_off = [&](int t, int s) -> int {
+        if constexpr (FULLTAB) {
+            return pB[t][s];
+        } else {
+            int dy, dx, ioy, iox;
+            decode_tap(a.taps[t], dy, dx, ioy, iox);
+            const int prow = (wave + 1 + dy) * PW + (frow + 1 + dx);
+            return prow * 128 + (((2 * s + fk) ^ ((prow >> 1) & 7)) << 4);
+        }
+    };
+    int wA[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wA[s] = frow * 128 + (((2 * s + fk) ^ ((frow >> 1) & 7)) << 4);
+    constexpr int NPASS = PR_PAD / RP;
+    int dpy[FULLTAB ? NPASS : 1], dpx[FULLTAB ? NPASS : 1];
+    auto patch_row = [&](int pass, int& py_, int& px_) {
+        const int r = pass * RP + srow;
+        const int pyy = r / PW;
+        py_ = r < PR ? pyy - 1 : -100000;                     // rows beyond the patch fail every bounds test
+        px_ = r - pyy * PW - 1;
+    };
+    if constexpr (FULLTAB) {
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) patch_row(pass, dpy[pass], dpx[pass]);
+    }
+
     auto tile_origin = [&](int tile, int& n, int& y0, int& x0) {
         const int tx = tile % tiles_x;
         tile /= tiles_x;
@@ -506,14 +554,17 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
         const bool kok = cv < a.KV;
         int seg, seg_end; const char* sp; uint32_t sb, coffB;
         pick_seg_b(a, kok ? cv : 0, VEC * ES, seg, sp, sb, coffB, seg_end);
+        const char* base = sp + coffB;
+        const int org = (n * a.Hx + y0) * a.Wx + x0;            // uniform: pixel index of the tile origin
 #pragma unroll
-        for (int pass = 0; pass < PR_PAD / RP; ++pass) {
-            const int r = pass * RP + srow;
-            const int pyy = r / PW, pxx = r - pyy * PW;
-            const int iy = y0 - 1 + pyy, ix = x0 - 1 + pxx;
-            const bool ok = kok && r < PR && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx;
+        for (int pass = 0; pass < NPASS; ++pass) {
+            int py_, px_;
+            if constexpr (FULLTAB) { py_ = dpy[pass]; px_ = dpx[pass]; }
+            else patch_row(pass, py_, px_);
+            const int iy = y0 + py_, ix = x0 + px_;
+            const bool ok = kok && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx;
             const char* src = zero;
-            if (ok) src = sp + (size_t)((uint32_t)((n * a.Hx + iy) * a.Wx + ix) * sb) + coffB;
+            if (ok) src = base + (size_t)((uint32_t)(org + py_ * a.Wx + px_) * sb);
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sP + (pass * RP + wave * 8) * 128), 16, 0, 0);
         }
     };
@@ -531,26 +582,71 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
     };
     // nks: k-steps of this channel chunk that hold real channels (2 vectors each); the rest of the 128-byte row is zero
     // fill (conv1: 40 of 64 channels, get_depth / the conv1 data-gradients: 32, get_depth's data-gradient: 8), so skipping
-    // it changes nothing but the MFMA and ds_read count
-    auto compute = [&](const char* sP, f32x16_t (&acc)[NG], int nks) {
+    // it changes nothing but the MFMA and ds_read count.  The count is a compile-time constant of the body (dispatched once per
+    // call below): a run-time `if (s >= nks) break` splits the tap loop into basic blocks and hipcc then waits lgkmcnt(0) in
+    // front of every single MFMA.  Fragments are read one (tap, k-step) ahead of the MFMA that consumes them.
+    auto compute_n = [&](const char* sP, f32x16_t (&acc)[NG], auto nks_c) {
+        constexpr int NKS = decltype(nks_c)::value;
+        constexpr int NQ = TPG * NKS;
+        constexpr int D = 2;                                      // fragment pairs in flight ahead of the MFMA that consumes them
+        if constexpr (!FULLTAB) {
+            // 16-tap sub-pixel variants (4 accumulators): the hand-placed form below costs them ~60 more registers than they
+            // have (spills); they keep compiler-scheduled loads, straight-line in the k-step count
+            int lo = 0;
+            asm volatile("" : "+v"(lo));          // keeps the 64 + 64 fragment addresses out of LICM's hands (registers)
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
+            for (int g = 0; g < NG; ++g) {
 #pragma unroll
-            for (int t = 0; t < TPG; ++t) {
-                int dy, dx, ioy, iox;
-                decode_tap(a.taps[g * TPG + t], dy, dx, ioy, iox);
-                const int prow = (wave + 1 + dy) * PW + (frow + 1 + dx);
-                const int wrow = (g * TPG + t) * 32 + frow;
-                const int pswz = (prow >> 1) & 7, wswz = (wrow >> 1) & 7;
+                for (int t = 0; t < TPG; ++t) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    if (s >= nks) break;
-                    const u32x4_t fb = *(const u32x4_t*)(sP + prow * 128 + (((2 * s + fk) ^ pswz) << 4));
-                    const u32x4_t fa = *(const u32x4_t*)(sW + wrow * 128 + (((2 * s + fk) ^ wswz) << 4));
-                    Mma<T>::run(fa, fb, acc[g]);
+                    for (int s = 0; s < NKS; ++s) {
+                        const u32x4_t fb = *(const u32x4_t*)(sP + lo + pb_off(g * TPG + t, s));
+                        const u32x4_t fa = *(const u32x4_t*)(sW + lo + (g * TPG + t) * 32 * 128 + wA[s]);
+                        Mma<T>::run(fa, fb, acc[g]);
+                    }
                 }
             }
+            return;
         }
+        // reads from inline asm + counted lgkmcnt: with compiler-visible loads hipcc pairs each MFMA with a fragment it has
+        // only just requested and waits lgkmcnt(0) in front of every MFMA (checked in the ISA), i.e. no read-ahead at all
+        uint32_t sPa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)sP;
+        uint32_t sWa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)sW;
+        // opaque to LICM: otherwise all NT x 4 x 2 fragment addresses are hoisted out of the chunk / tile loop as invariants
+        // (128 live registers in the 16-tap variants -> spills); one v_add per read is the cheaper side of that trade
+        asm volatile("" : "+v"(sPa), "+v"(sWa));
+        auto rd = [&](u32x4_t& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); };
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            u32x4_t fa[D + 1], fb[D + 1];
+#pragma unroll
+            for (int q = 0; q < D && q < NQ; ++q) {
+                rd(fb[q], sPa + pb_off(g * TPG + q / NKS, q % NKS));
+                rd(fa[q], sWa + (g * TPG + q / NKS) * 32 * 128 + wA[q % NKS]);
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q + D < NQ) {
+                    rd(fb[(q + D) % (D + 1)], sPa + pb_off(g * TPG + (q + D) / NKS, (q + D) % NKS));
+                    rd(fa[(q + D) % (D + 1)], sWa + (g * TPG + (q + D) / NKS) * 32 * 128 + wA[(q + D) % NKS]);
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * D) : "memory");
+                } else if (q + 1 < NQ && D > 1) {
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");   // tail: one pair still behind this one
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                Mma<T>::run(fa[q % (D + 1)], fb[q % (D + 1)], acc[g]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto compute = [&](const char* sP, f32x16_t (&acc)[NG], int nks) {
+        if constexpr (!FULLTAB) { compute_n(sP, acc, std::integral_constant<int, 4>()); return; }   // one body: registers
+        if (nks >= 4) compute_n(sP, acc, std::integral_constant<int, 4>());
+        else if (nks == 3) compute_n(sP, acc, std::integral_constant<int, 3>());
+        else if (nks == 2) compute_n(sP, acc, std::integral_constant<int, 2>());
+        else compute_n(sP, acc, std::integral_constant<int, 1>());
     };
     // lane = pixel (x0 + frow) of tile row `wave`, registers = channels
     auto epilogue = [&](const f32x16_t (&acc)[NG], int n, int y0, int x0) {
