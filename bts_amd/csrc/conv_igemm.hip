@@ -711,27 +711,42 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
         const int per = (ntiles + gridDim.x - 1) / gridDim.x;
         const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
         if (t_begin >= t_end) return;
+        // Pipeline (r2).  State at the top of iteration i: patch i has landed and is published, the DMA of patch i+1 is in
+        // flight into the other buffer.  compute(i); then ONE wait + barrier: the wait retires this wave's pieces of patch i+1
+        // (issued a whole iteration ago) and the output stores of tile i-1 (issued a whole compute() ago), the barrier publishes
+        // patch i+1 and frees buffer i, whose refill (patch i+2) is issued before the epilogue of tile i.  Round 1 waited at the
+        // TOP of the iteration, i.e. directly behind the previous tile's stores: their full write latency was exposed on every
+        // tile (SQ counters: waves parked 52 % of their cycles).  Accumulating epilogues read the old value, and hipcc drains
+        // vmcnt(0) before using it, so there the refill is issued after the epilogue instead.
         dma_weights(0);
         int n, y0, x0;
         tile_origin(t_begin, n, y0, x0);
         dma_patch(0, n, y0, x0, smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                             // weights + patch 0 landed
+        int n1 = 0, y1 = 0, x1 = 0;
+        if (t_begin + 1 < t_end) {
+            tile_origin(t_begin + 1, n1, y1, x1);
+            dma_patch(0, n1, y1, x1, smem + PR_PAD * 128);
+        }
         for (int tile = t_begin; tile < t_end; ++tile) {
             const int cur = (tile - t_begin) & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                         // patch `cur` (and the weights) landed; buffer cur^1 is free
-            int nn = 0, ny0 = 0, nx0 = 0;
-            if (tile + 1 < t_end) {
-                tile_origin(tile + 1, nn, ny0, nx0);
-                dma_patch(0, nn, ny0, nx0, smem + (cur ^ 1) * PR_PAD * 128);
-            }
             f32x16_t acc[NG];
 #pragma unroll
             for (int g = 0; g < NG; ++g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
             compute(smem + cur * PR_PAD * 128, acc, (min(a.KV, 8) + 1) >> 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                         // patch tile+1 landed everywhere; buffer `cur` is free
+            int n2 = 0, y2 = 0, x2 = 0;
+            const bool more = tile + 2 < t_end;
+            if (more) tile_origin(tile + 2, n2, y2, x2);
+            if (more && !a.accumulate) dma_patch(0, n2, y2, x2, smem + cur * PR_PAD * 128);
             epilogue(acc, n, y0, x0);
-            n = nn; y0 = ny0; x0 = nx0;
+            if (more && a.accumulate) dma_patch(0, n2, y2, x2, smem + cur * PR_PAD * 128);
+            n = n1; y0 = y1; x0 = x1;
+            n1 = n2; y1 = y2; x1 = x2;
         }
     } else {
         int n, y0, x0;
