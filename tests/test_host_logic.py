@@ -99,4 +99,5 @@ def test_profiler_labels_follow_dispatch():
     assert conv._wgrad_kernel(bf, 32, True, True, 8, 176, 608) == "conv_wgrad_halo_up<bf16>"
     assert conv._wgrad_kernel(f32, 32, True, False, 8, 352, 1216) == "conv_wgrad<f32,32x128k4>"
     assert conv._wgrad_kernel(bf, 32, True, False, 1, 32, 64) == "conv_wgrad<bf16,32x128k4>"      # < 256 tiles
-    assert conv._wgrad_kernel(bf, 512, True, False, 8, 22, 76) == "conv_wgrad<bf16,128x128>"
+    assert conv._wgrad_kernel(bf, 512, True, False, 8, 22, 76) == "conv_wgrad_tr<bf16,128x128>"    # wide bf16: LDS-DMA + transposing reads
+    assert conv._wgrad_kernel(f32, 512, True, False, 8, 22, 76) == "conv_wgrad<f32,128x128>"
