@@ -419,8 +419,8 @@ def main():
     for _ in range(2):
         step()
     prof = None
-    if not args.no_kernel_events and rank == 0 and graph is None:
-        prof = profiler.enable()
+    if not args.no_kernel_events and rank == 0 and graph is None and world == 1:
+        prof = profiler.enable()      # N > 1: never inside the timed region (per-launch events on one rank would hold back all of them)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -436,7 +436,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss.item())
-    if graph is not None and not args.no_kernel_events and (rank == 0 or world > 1):
+    if (graph is not None or world > 1) and not args.no_kernel_events and (rank == 0 or world > 1):
         # events cannot be recorded inside a graph replay: time the same kernels over the same number of
         # eager steps right after the timed region (same process, same buffers, same clocks).  With N > 1 every rank runs
         # these steps (their collectives must match); only rank 0 records.

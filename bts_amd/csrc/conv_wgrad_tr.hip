@@ -221,20 +221,14 @@ int launch_wgrad_tr(const ConvK& k0, hipStream_t st) {
     k.n_col_tiles = ceil_div((long)k.T * k.Ktot, 128);
     k.nchunks = ceil_div(k.M, KC);
     const int tiles = k.n_co_tiles * k.n_col_tiles * k.nphase;
-    // Pixel split: as shallow as possible, chosen by a wave-quantisation model -- the chip holds `slots` workgroups at a time
-    // (2 per CU: 64 KiB of LDS each), a launch of tiles*s workgroups runs in ceil(tiles*s/slots) rounds of ceil(nchunks/s)
-    // chunks (+ ~3 chunks of pipeline fill / epilogue / atomics per workgroup).  conv5: 252 tiles -> s = 2 (one round of 105
-    // chunks); upconv5: 1104 tiles -> s = 3 (7 rounds of 18 instead of 3 rounds of 53: -12 %); BTS_WGRAD_TR_WGS overrides slots.
-    static const int slots = [] { const char* e = getenv("BTS_WGRAD_TR_WGS"); return e ? atoi(e) : 512; }();   // A/B knob
-    int splits = 1;
-    long best = -1;
-    for (int sp = 1; sp <= 32; ++sp) {
-        const int per = ceil_div(k.nchunks, sp);
-        if (sp > 1 && per < 4) break;
-        const long rounds = ceil_div((long)tiles * sp, slots);
-        const long cost = rounds * (per + 3);
-        if (best < 0 || cost < best) { best = cost; splits = sp; }
-    }
+    // Pixel split: only until the chip is full -- `slots` workgroups at a time (2 per CU: 64 KiB of LDS each).  conv5: 252
+    // tiles -> 2 splits (one round of 105 chunks); layers with more tiles than slots are not split at all: a wave-quantisation
+    // model that split upconv5 (1104 tiles) 3-way to even out its rounds measured 269 us against 250 us unsplit (r02l) -- the
+    // 212 MB of extra f32 atomics cost more than the idle tail.  BTS_WGRAD_TR_WGS overrides slots (A/B).
+    static const int slots = [] { const char* e = getenv("BTS_WGRAD_TR_WGS"); return e ? atoi(e) : 512; }();
+    int splits = slots / tiles;
+    if (splits > k.nchunks / 4) splits = k.nchunks / 4;          // >= 4 chunks per workgroup
+    if (splits < 1) splits = 1;
     k.chunks_per_split = ceil_div(k.nchunks, splits);
     splits = ceil_div(k.nchunks, k.chunks_per_split);
     dim3 grid(k.n_co_tiles * k.n_col_tiles, splits, k.nphase);
