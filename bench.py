@@ -247,6 +247,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     multi = world > 1 or bool(args.force_dist)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    local = local % torch.cuda.device_count()      # (plumbing tests run several ranks on one GPU over gloo)
+    torch.cuda.set_device(local)                   # before the process group: RCCL binds the communicator to the current device
     if world > 1:
         dist.init_process_group(backend=args.backend, init_method="env://")
     elif multi:
@@ -256,9 +259,6 @@ def main():
         port = sk.getsockname()[1]
         sk.close()
         dist.init_process_group(backend=args.backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    local = local % torch.cuda.device_count()      # (plumbing tests run several ranks on one GPU over gloo)
-    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     from bts_amd import _lib, profiler
