@@ -56,10 +56,27 @@ def _cdiv(a, b):
     return (a + b - 1) // b
 
 
-def _fwd_kernel(dtype, cout, halo):
+def _wide_pays(cout, n, hg, wg):
+    """Mirrors launch_halo_wide()'s fill heuristic (csrc/conv_halo_wide.hip)."""
+    mode = os.environ.get("BTS_CONV_WIDE", "1")[:1]
+    if mode == "0":
+        return False
+    if mode == "2":
+        return True
+    ntiles = _cdiv(wg, 32) * _cdiv(hg, 8) * n
+    nco = _cdiv(cout, 128)
+    wgs = ntiles * nco
+    rounds = _cdiv(wgs, 256)
+    fill = (hg * wg * n / (ntiles * 256.0)) * (cout / (nco * 128.0)) * (wgs / (rounds * 256.0))
+    return fill >= 0.70
+
+
+def _fwd_kernel(dtype, cout, halo, geom=None, kv=8, up=False):
     """Name of the kernel launch_fwd() (csrc/conv_igemm.hip) picks: profiler label = rocprofv3 kernel family."""
     if halo and cout <= 64:
         return "conv_halo<%s>" % _dn(dtype)
+    if halo and not up and dtype == torch.bfloat16 and kv >= 8 and geom is not None and _wide_pays(cout, *geom):
+        return "conv_halo_wide<bf16,128x256>"
     return "conv_igemm_dma<%s,%s>" % (_dn(dtype), "128x128" if cout > 64 else ("64x128" if cout > 32 else "32x256"))
 
 
@@ -180,7 +197,8 @@ class ConvLayer:
         d.accumulate = 0
         if profiler.ACTIVE is not None:
             M = N * Hx * Wx
-            profiler.note(_fwd_kernel(dtype, self.cout, self.kk == 9 and self.dil == 1), "mfma",
+            kv = sum(pad_to(c, vec_of(dtype)) for c in self.seg_channels) // vec_of(dtype)
+            profiler.note(_fwd_kernel(dtype, self.cout, self.kk == 9 and self.dil == 1, (N, Hx, Wx), kv, self.up), "mfma",
                           2.0 * M * self.nphase * self.T * self.cin * self.cout)
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return out
@@ -218,7 +236,8 @@ class ConvLayer:
         d.accumulate = int(accumulate)
         if profiler.ACTIVE is not None:
             cseg = self.seg_channels[seg_index]
-            profiler.note(_fwd_kernel(dtype, gx.shape[3], self.kk == 9 and self.dil == 1 and not self.up), "mfma",
+            profiler.note(_fwd_kernel(dtype, gx.shape[3], self.kk == 9 and self.dil == 1 and not self.up, (N, Hg, Wg),
+                                      pad_to(self.cout, vec_of(dtype)) // vec_of(dtype)), "mfma",
                           2.0 * N * Hg * Wg * len(self.taps) * cseg * self.cout)
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return gx

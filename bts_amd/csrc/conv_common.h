@@ -202,6 +202,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16_t (&acc)[TM
 // BTS_ERR_UNSUPPORTED outside its domain (the caller then uses conv_igemm_dma).
 int launch_fwd_pp(const ConvK& k, hipStream_t st, int variant);
 
+// conv_halo_wide.hip: 3x3 radius-1 forward / data-gradient with > 64 output channels on 2-D pixel tiles (patch staged once
+// per channel chunk, weights streamed per tap); BTS_ERR_UNSUPPORTED outside its domain.
+int launch_halo_wide(const ConvK& k, hipStream_t st, int force);
+
 // conv_wgrad_tr.hip: bf16 weight gradient of the wide layers (LDS-DMA staging + transpose reads); returns BTS_ERR_UNSUPPORTED
 // when the shape is outside its domain (the caller then falls back to conv_wgrad).
 int launch_wgrad_tr(const ConvK& k, hipStream_t st);

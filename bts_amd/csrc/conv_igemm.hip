@@ -1733,6 +1733,13 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
         BTS_LAUNCH_CHECK();
         return BTS_OK;
     }
+    // wide radius-1 3x3 layers: 2-D pixel tile with halo + per-tap weight streaming (conv_halo_wide.hip); BTS_CONV_WIDE=0|1 (A/B)
+    // (0 = off, 1 = where its fill heuristic says it pays [default], 2 = wherever it is applicable)
+    static const int wide_on = [] { const char* e = getenv("BTS_CONV_WIDE"); return e ? atoi(e) : 1; }();
+    if (wide_on && use_lds_dma() && T::kBytes == 2 && k.halo_ok && k.Cout > 64 && k.nphase == 1 && k.T == 9 && k.KV >= 8) {
+        const int rc = launch_halo_wide(k, st, wide_on >= 2);
+        if (rc != BTS_ERR_UNSUPPORTED) return rc;
+    }
     if (use_lds_dma()) {
         // K order (see conv_igemm_dma): channel-chunk-major whenever it costs no padding; BTS_CONV_KMAJOR=0 for A/B
         static const int kmajor_on = [] { const char* e = getenv("BTS_CONV_KMAJOR"); return (e && e[0] == '0') ? 0 : 1; }();

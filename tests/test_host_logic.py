@@ -92,6 +92,12 @@ def test_profiler_labels_follow_dispatch():
     from bts_amd import conv
     bf, f32 = torch.bfloat16, torch.float32
     assert conv._fwd_kernel(bf, 512, True) == "conv_igemm_dma<bf16,128x128>"
+    # wide radius-1 layers: 2-D halo tiles with per-tap weight streaming where the tiles fill the chip (conv4 / conv3 / daspp_conv
+    # at the train shape), implicit GEMM where they do not (conv5: 22x76 map, 288 workgroups)
+    assert conv._fwd_kernel(bf, 256, True, (8, 44, 152), 56) == "conv_halo_wide<bf16,128x256>"
+    assert conv._fwd_kernel(bf, 128, True, (8, 88, 304), 29) == "conv_halo_wide<bf16,128x256>"
+    assert conv._fwd_kernel(bf, 512, True, (8, 22, 76), 112) == "conv_igemm_dma<bf16,128x128>"
+    assert conv._fwd_kernel(torch.float32, 256, True, (8, 44, 152), 112) == "conv_igemm_dma<f32,128x128>"
     assert conv._fwd_kernel(bf, 32, True) == "conv_halo<bf16>"
     assert conv._fwd_kernel(bf, 32, False) == "conv_igemm_dma<bf16,32x256>"
     assert conv._wgrad_kernel(bf, 1, True, False, 8, 352, 1216) == "conv_wgrad_c1<bf16>"
