@@ -362,7 +362,46 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");   // this wave's part of `chunk` has landed
         __builtin_amdgcn_s_barrier();                                          // everyone's has; buffer wbuf is free
         const char* sT = smem + rbuf * BUF;
-        if constexpr (PF >= 6) {
+        if constexpr (PF >= 8 && TM == 2 && TN == 2) {
+            // Fine interleave (the lever on conv_halo_wide: +10 % there): the reads of k-step s+1 and the chunk's 8 DMA issues sit
+            // between the individual MFMAs of k-step s, one or two per MFMA shadow, instead of in blocks in front of them.
+            const uint32_t sTa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem + rbuf * BUF;
+            char* sAw = smem + wbuf * BUF;
+            char* sBw = sAw + BM * 128;
+            u32x4_t fa[2][TM], fb[2][TN];
+            auto rd = [&](u32x4_t& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); };
+            auto rdA = [&](int set, int i, int s) { rd(fa[set][i], sTa + offA[i] + (((2 * s + fk) ^ swz) << 4)); };
+            auto rdB = [&](int set, int j, int s) { rd(fb[set][j], sTa + offB[j] + (((2 * s + fk) ^ swz) << 4)); };
+            auto dmaA = [&](int i) { __builtin_amdgcn_global_load_lds((gptr_t)srcA[i], (lptr_t)(sAw + (wave * 8 + RP * i) * 128), 16, 0, 0); };
+            auto dmaB = [&](int i) { __builtin_amdgcn_global_load_lds((gptr_t)srcB[i], (lptr_t)(sBw + (wave * 8 + RP * i) * 128), 16, 0, 0); };
+            auto mm = [&](int set, int i, int j) {
+                __builtin_amdgcn_sched_barrier(0);
+                Mma<T>::run(fa[set][i], fb[set][j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            static_assert(RA == 4 && RB == 4, "8 DMA instructions per thread per chunk");
+            rdA(0, 0, 0); rdA(0, 1, 0); rdB(0, 0, 0); rdB(0, 1, 0);
+            dmaA(0); dmaA(1);                                        // in the latency shadow of the first reads
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_setprio(1);
+            mm(0, 0, 0); rdA(1, 0, 1); rdA(1, 1, 1);
+            mm(0, 0, 1); rdB(1, 0, 1); rdB(1, 1, 1);
+            mm(0, 1, 0); dmaA(2); dmaA(3);
+            mm(0, 1, 1); dmaB(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mm(1, 0, 0); rdA(0, 0, 2); rdA(0, 1, 2);
+            mm(1, 0, 1); rdB(0, 0, 2); rdB(0, 1, 2);
+            mm(1, 1, 0); dmaB(1); dmaB(2);
+            mm(1, 1, 1); dmaB(3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mm(0, 0, 0); rdA(1, 0, 3); rdA(1, 1, 3);
+            mm(0, 0, 1); rdB(1, 0, 3); rdB(1, 1, 3);
+            mm(0, 1, 0);
+            mm(0, 1, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mm(1, 0, 0); mm(1, 0, 1); mm(1, 1, 0); mm(1, 1, 1);
+            __builtin_amdgcn_s_setprio(0);
+        } else if constexpr (PF >= 6) {
             // Whole-chunk fragment prefetch with the LDS reads issued from inline asm and COUNTED lgkmcnt waits.  hipcc waits
             // lgkmcnt(0) at the first MFMA behind a batch of LDS-DMA instructions (it did so in the read-ahead form above as
             // well: the "read-ahead" k-step was always waited for together with the current one), so with compiler-visible
@@ -1760,12 +1799,15 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
         //      all 16 reads are waited for before the first MFMA: +-0 %
         //   r/s the same with the ds_read_b128 issued from inline asm and counted lgkmcnt(12/8/4/0) (+ s_setprio 1 around the 16
         //      MFMAs): +3..10 % per layer over a on one box (r2: conv5 713 -> 749 TF, conv4 dgrad 578 -> 638, conv3 490 -> 517,
-        //      daspp_conv 712 -> 748).  DEFAULT = s.
+        //      daspp_conv 712 -> 748).
+        //   t  s with the reads of k-step s+1 and the chunk's 8 DMA issues placed BETWEEN the individual MFMAs of k-step s (one or
+        //      two per MFMA shadow): +5..11 % over s on every layer of the same box (r02t: conv5 714 -> 768, daspp_conv 721 -> 778,
+        //      daspp 1x1 395 -> 439, conv4 652 -> 700).  DEFAULT = t.
         //   x/y/z conv_igemm_pp.hip: two staggered wave groups, 128x256 (x, z = DMA issue between the MFMAs) / 256x256 (y): parity-
         //      green, slower (x: -8 %) or layer-dependent (y: conv4 +8 %, conv5 -38 %); see DESIGN section 9 (the LDS-DMA fill rate of
         //      ~20 B/clk/CU, not the overlap structure, is the limiter, and 256-wide tiles do not fill 256 CUs at these shapes)
         //   64co x 128px and 32co x 256px, 4 waves, 2 stages for narrow layers
-        static const char big = [] { const char* e = getenv("BTS_CONV_BIG"); return e ? e[0] : 's'; }();   // A/B knob (s = default)
+        static const char big = [] { const char* e = getenv("BTS_CONV_BIG"); return e ? e[0] : 't'; }();   // A/B knob (t = default)
         if (k.Cout > 64 && T::kBytes == 2 && (big == 'x' || big == 'y' || big == 'z')) {     // staggered wave groups (conv_igemm_pp.hip)
             const int rc = launch_fwd_pp(k, st, big == 'z' ? 3 : (big == 'y' && k.Cout >= 256) ? 4 : 2);
             if (rc != BTS_ERR_UNSUPPORTED) return rc;
@@ -1781,7 +1823,8 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
             else if (big == 'r') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 6>, 128, 128, 256);    // asm reads, counted lgkmcnt
             else if (big == 's') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 7>, 128, 128, 256);    // + s_setprio
             else if (big == 'a') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2>, 128, 128, 256);       // round-1 schedule (compiler-placed waits)
-            else go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 7>, 128, 128, 256);                    // default: s
+            else if (big == 's') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 7>, 128, 128, 256);
+            else go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8>, 128, 128, 256);                    // default: t
         }
         else if (k.Cout > 32) go2(conv_igemm_dma<T, 1, 4, 2, 1, 2>, 64, 128, 256);
         else go2(conv_igemm_dma<T, 1, 4, 1, 2, 2>, 32, 256, 256);
