@@ -1601,15 +1601,24 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const bts_pack_j
     if (tid < PACK_TILE) ci_s[tid] = e0 + tid < NE ? j.cmap[e0 + tid] : -1;
     if (tid >= 64 && tid < 64 + BTS_MAX_TAP) mask_s[tid - 64] = tid - 64 < Tn ? j.tapmask[tid - 64] : 0u;
     __syncthreads();
-    const int run = PACK_TILE * KK;
-    for (int i = tid; i < PACK_TILE * run; i += 256) {
-        const int co = i / run, rem = i - co * run;
-        const int e = rem / KK, sidx = rem - e * KK;
-        const int ci = ci_s[e];
-        float v = 0.f;
-        if (ci >= 0 && co0 + co < Cout) v = j.w[((size_t)(co0 + co) * Cin + ci) * KK + sidx];
-        tile[co * PACK_ROW + rem] = v;
-    }
+    // the index split below runs 36 times per thread: with KK a compile-time constant (3x3 and 1x1 are the only kernel
+    // sizes of the decoder) the two divisions are multiply-shifts instead of ~40-instruction software divisions, which
+    // made this kernel VALU-bound at under 1 TB/s
+    auto load_tile = [&](auto kkc) {
+        const int kk = decltype(kkc)::value ? decltype(kkc)::value : KK;
+        const int run = PACK_TILE * kk;
+        for (int i = tid; i < PACK_TILE * run; i += 256) {
+            const int co = i / run, rem = i - co * run;
+            const int e = rem / kk, sidx = rem - e * kk;
+            const int ci = ci_s[e];
+            float v = 0.f;
+            if (ci >= 0 && co0 + co < Cout) v = j.w[((size_t)(co0 + co) * Cin + ci) * kk + sidx];
+            tile[co * PACK_ROW + rem] = v;
+        }
+    };
+    if (KK == 9) load_tile(std::integral_constant<int, 9>{});
+    else if (KK == 1) load_tile(std::integral_constant<int, 1>{});
+    else load_tile(std::integral_constant<int, 0>{});
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < PACK_TILE * PACK_TILE / 256; ++q) {

@@ -26,11 +26,26 @@ __device__ __forceinline__ void thread_coords(int bx_log2, int& cv, long& p0, lo
     pstep = (long)gridDim.x * by;
 }
 
+// Launch-shape parameters of the streaming kernels.  Values chosen from the sweep of tools/probes/ew_probe.hip on an
+// MI355X (profiles/r02_ew_probe.jsonl); the probe includes this file with BTS_EW_PROBE defined and varies them.
+#ifdef BTS_EW_PROBE
+#define BTS_EW_TUNABLE static int
+#else
+#define BTS_EW_TUNABLE static constexpr int
+#endif
+BTS_EW_TUNABLE g_vpt = 4;             // 16-byte vectors each thread of a pixel-strided kernel should own
+BTS_EW_TUNABLE g_max_blocks = 65536;  // ... within [256, g_max_blocks] workgroups
+BTS_EW_TUNABLE g_part_blocks = 512;   // upper bound of the partial-sum rows of the two-pass reductions
+BTS_EW_TUNABLE g_final_lanes = 32;    // partial-row lanes per channel in bn_stats_final_kernel (8 or 32)
+BTS_EW_TUNABLE g_unroll4 = 1;         // 1: four instead of two pixel iterations of loads in flight per thread
+BTS_EW_TUNABLE g_wide_transpose = 1;  // 1: 64x64-tile bf16 layout conversions with 16-byte accesses on both sides
+
 // Grid for the pixel-strided elementwise kernels.  Every thread first loads its per-channel constants (up to 48
-// scalars for the BatchNorm backward), so it must own enough pixels to amortise that prologue: aim at >= 8 vectors
-// per thread, within [256, max_blocks] workgroups (one wave of workgroups per CU is enough to saturate HBM once each
-// thread keeps two iterations of loads in flight, see the `#pragma unroll 2` loops).
-static void pick_grid(long M, int CV, int& bx_log2, dim3& grid, int max_blocks = 2048, bool fixed = false) {
+// scalars for the BatchNorm backward), so it should own a few pixels to amortise that prologue, but the tensors of
+// the decoder are small (14-55 MB at 1/8 resolution): the grid must still put several workgroups on each of the
+// 256 CUs, or the kernel is bound by the latency of the few loads each CU has in flight, not by HBM.
+static void pick_grid(long M, int CV, int& bx_log2, dim3& grid, int max_blocks = 0, bool fixed = false) {
+    if (max_blocks <= 0) max_blocks = g_max_blocks;
     bx_log2 = 0;
     while ((1 << bx_log2) < CV && bx_log2 < 5) ++bx_log2;
     const int bx = 1 << bx_log2, by = 256 >> bx_log2;
@@ -38,7 +53,8 @@ static void pick_grid(long M, int CV, int& bx_log2, dim3& grid, int max_blocks =
     long gx = (M + by - 1) / by;
     long blocks = max_blocks;
     if (!fixed) {
-        const long want = (M * (long)gy * bx + 256l * 8 - 1) / (256l * 8);
+        const long per = 256l * g_vpt;
+        const long want = (M * (long)gy * bx + per - 1) / per;
         blocks = want < 256 ? 256 : (want > max_blocks ? max_blocks : want);
     }
     const long cap = blocks / gy > 0 ? blocks / gy : 1;
@@ -56,59 +72,65 @@ __device__ __forceinline__ void stv(void* base, size_t elem_off, const float* f)
     *(u32x4_t*)((char*)base + elem_off * T::kBytes) = T::pack(f);
 }
 
+// The pixel loops below issue the 16-byte loads of U pixel iterations back to back before any of them is consumed
+// (U x 1..3 loads in flight per thread), with every mode flag a template parameter or a select: run-time branches
+// inside the loop made hipcc serialise load -> wait -> compute -> store per iteration, which left these kernels bound
+// by the latency of two loads per thread instead of by HBM.
+__device__ __forceinline__ u32x4_t ld16(const char* base, long p, size_t step) { return *(const u32x4_t*)(base + (size_t)p * step); }
+__device__ __forceinline__ void st16(char* base, long p, size_t step, const u32x4_t& v) { *(u32x4_t*)(base + (size_t)p * step) = v; }
+
 // ---- y = act(x*scale + shift) ------------------------------------------------------------------
-template <typename TX, typename TY>
+template <typename T, int U, bool TAB>   // TAB: both tables given (the BatchNorm apply); else either may be null
 __global__ __launch_bounds__(256) void affine_act_kernel(const void* __restrict__ x, int xs, void* __restrict__ y, int ys,
                                                          Shape2 s, int bxl, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int act) {
-    static_assert(TX::kVec == TY::kVec, "same vector width");
-    constexpr int V = TX::kVec;
+    constexpr int V = T::kVec;
     int cv; long p, ps;
     thread_coords(bxl, cv, p, ps, s);
     if (cv >= s.CV) return;
     float sc[V], sh[V];
 #pragma unroll
-    for (int e = 0; e < V; ++e) { sc[e] = scale ? scale[cv * V + e] : 1.f; sh[e] = shift ? shift[cv * V + e] : 0.f; }
-#pragma unroll 2
-    for (; p < s.M; p += ps) {
+    for (int e = 0; e < V; ++e) {
+        if (TAB) { sc[e] = scale[cv * V + e]; sh[e] = shift[cv * V + e]; }     // unconditional: all in flight together
+        else { sc[e] = scale ? scale[cv * V + e] : 1.f; sh[e] = shift ? shift[cv * V + e] : 0.f; }
+    }
+    const bool relu = act == BTS_ACT_RELU;
+    const char* xb = (const char*)x + (size_t)cv * 16;
+    char* yb = (char*)y + (size_t)cv * 16;
+    const size_t xst = (size_t)xs * T::kBytes, yst = (size_t)ys * T::kBytes;
+    auto one = [&](const u32x4_t& v, long q) {
         float f[V];
-        ldv<TX>(x, (size_t)p * xs + cv * V, f);
+        T::unpack(v, f);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            float t = f[e] * sc[e] + sh[e];
-            if (act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
-            f[e] = t;
+            const float t = f[e] * sc[e] + sh[e];
+            f[e] = relu ? fmaxf(t, 0.f) : t;
         }
-        stv<TY>(y, (size_t)p * ys + cv * V, f);
+        st16(yb, q, yst, T::pack(f));
+    };
+    for (; p + (U - 1) * ps < s.M; p += U * ps) {
+        u32x4_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ld16(xb, p + u * ps, xst);
+        __builtin_amdgcn_sched_barrier(0);    // keep the whole batch of loads in front of their first use
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(v[u], p + u * ps);
     }
+    for (; p < s.M; p += ps) one(ld16(xb, p, xst), p);
 }
 
 // ---- batch statistics --------------------------------------------------------------------------
-// pass 1: per-block partial sums  ws[block][2][Cpad]
-template <typename T>
-__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const void* __restrict__ x, int xs, Shape2 s, int bxl,
-                                                               float* __restrict__ ws, int Cpad) {
-    constexpr int V = T::kVec;
-    int cv; long p, ps;
-    thread_coords(bxl, cv, p, ps, s);
-    float a[V], b[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) a[e] = b[e] = 0.f;
-    if (cv < s.CV) {
-        for (; p < s.M; p += ps) {
-            float f[V];
-            ldv<T>(x, (size_t)p * xs + cv * V, f);
-#pragma unroll
-            for (int e = 0; e < V; ++e) { a[e] += f[e]; b[e] += f[e] * f[e]; }
-        }
-    }
-    // reduce over the pixel lanes (ty) of the block through LDS
+// reduce the per-thread sums over the pixel lanes (ty) of the block through LDS and store row blockIdx.x of
+// ws[part][2][Cpad]
+template <int V>
+__device__ __forceinline__ void block_partials_out(const float* a, const float* b, int bxl, int cv, int CV,
+                                                   float* __restrict__ ws, int Cpad) {
     __shared__ float red[256][2 * 8 + 1];
 #pragma unroll
     for (int e = 0; e < V; ++e) { red[threadIdx.x][e] = a[e]; red[threadIdx.x][8 + e] = b[e]; }
     __syncthreads();
     const int bx = 1 << bxl, by = 256 >> bxl;
-    if (threadIdx.x < bx && cv < s.CV) {   // ty == 0 lanes
+    if (threadIdx.x < bx && cv < CV) {   // ty == 0 lanes
         for (int e = 0; e < V; ++e) {
             float sa = 0.f, sb = 0.f;
             for (int t = 0; t < by; ++t) { sa += red[t * bx + threadIdx.x][e]; sb += red[t * bx + threadIdx.x][8 + e]; }
@@ -118,11 +140,44 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const void* __res
     }
 }
 
+// pass 1: per-block partial sums  ws[block][2][Cpad]
+template <typename T, int U>
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const void* __restrict__ x, int xs, Shape2 s, int bxl,
+                                                               float* __restrict__ ws, int Cpad) {
+    constexpr int V = T::kVec;
+    int cv; long p, ps;
+    thread_coords(bxl, cv, p, ps, s);
+    float a[V], b[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] = b[e] = 0.f;
+    if (cv < s.CV) {
+        const char* xb = (const char*)x + (size_t)cv * 16;
+        const size_t xst = (size_t)xs * T::kBytes;
+        auto one = [&](const u32x4_t& v) {
+            float f[V];
+            T::unpack(v, f);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { a[e] += f[e]; b[e] += f[e] * f[e]; }
+        };
+        for (; p + (U - 1) * ps < s.M; p += U * ps) {
+            u32x4_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = ld16(xb, p + u * ps, xst);
+        __builtin_amdgcn_sched_barrier(0);    // keep the whole batch of loads in front of their first use
+#pragma unroll
+            for (int u = 0; u < U; ++u) one(v[u]);
+        }
+        for (; p < s.M; p += ps) one(ld16(xb, p, xst));
+    }
+    block_partials_out<V>(a, b, bxl, cv, s.CV, ws, Cpad);
+}
+
 // pass 2: combine partials in double. mode 0: out0 = mean, out1 = biased var ; mode 1: out0 = sum0, out1 = sum1
-// block = 32 channels x 8 partial-lanes: coalesced 128-byte reads of the partial rows, LDS tree at the end
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ ws, int nparts, int C, int Cpad,
-                                                             double M, int mode, float* __restrict__ out0,
-                                                             float* __restrict__ out1) {
+// block = 32 channels x L partial-lanes: coalesced 128-byte reads of the partial rows, LDS tree at the end
+template <int L>
+__global__ __launch_bounds__(32 * L) void bn_stats_final_kernel(const float* __restrict__ ws, int nparts, int C, int Cpad,
+                                                                double M, int mode, float* __restrict__ out0,
+                                                                float* __restrict__ out1) {
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double a = 0, b = 0;
@@ -130,22 +185,22 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
         // 4 independent accumulator pairs: the loop is latency-bound (each block owns only 32 channels)
         double a1 = 0, b1 = 0, a2 = 0, b2 = 0, a3 = 0, b3 = 0;
         int k = pl;
-        for (; k + 24 < nparts; k += 32) {
-            a += ws[((size_t)k * 2 + 0) * Cpad + c];          b += ws[((size_t)k * 2 + 1) * Cpad + c];
-            a1 += ws[((size_t)(k + 8) * 2 + 0) * Cpad + c];   b1 += ws[((size_t)(k + 8) * 2 + 1) * Cpad + c];
-            a2 += ws[((size_t)(k + 16) * 2 + 0) * Cpad + c];  b2 += ws[((size_t)(k + 16) * 2 + 1) * Cpad + c];
-            a3 += ws[((size_t)(k + 24) * 2 + 0) * Cpad + c];  b3 += ws[((size_t)(k + 24) * 2 + 1) * Cpad + c];
+        for (; k + 3 * L < nparts; k += 4 * L) {
+            a += ws[((size_t)k * 2 + 0) * Cpad + c];              b += ws[((size_t)k * 2 + 1) * Cpad + c];
+            a1 += ws[((size_t)(k + L) * 2 + 0) * Cpad + c];       b1 += ws[((size_t)(k + L) * 2 + 1) * Cpad + c];
+            a2 += ws[((size_t)(k + 2 * L) * 2 + 0) * Cpad + c];   b2 += ws[((size_t)(k + 2 * L) * 2 + 1) * Cpad + c];
+            a3 += ws[((size_t)(k + 3 * L) * 2 + 0) * Cpad + c];   b3 += ws[((size_t)(k + 3 * L) * 2 + 1) * Cpad + c];
         }
-        for (; k < nparts; k += 8) { a += ws[((size_t)k * 2 + 0) * Cpad + c]; b += ws[((size_t)k * 2 + 1) * Cpad + c]; }
+        for (; k < nparts; k += L) { a += ws[((size_t)k * 2 + 0) * Cpad + c]; b += ws[((size_t)k * 2 + 1) * Cpad + c]; }
         a += a1 + a2 + a3;
         b += b1 + b2 + b3;
     }
-    __shared__ double sa[8][33], sb[8][33];
+    __shared__ double sa[L][33], sb[L][33];
     sa[pl][cl] = a; sb[pl][cl] = b;
     __syncthreads();
     if (pl == 0 && c < C) {
 #pragma unroll
-        for (int k = 1; k < 8; ++k) { a += sa[k][cl]; b += sb[k][cl]; }
+        for (int k = 1; k < L; ++k) { a += sa[k][cl]; b += sb[k][cl]; }
         if (mode == 0) {
             const double mean = a / M;
             double var = b / M - mean * mean;
@@ -181,12 +236,11 @@ __global__ __launch_bounds__(256) void bn_prepare_kernel(const float* __restrict
 }
 
 // ---- BatchNorm(+ReLU) backward -------------------------------------------------------------------
-template <typename T>
+template <typename T, int U, bool RELU>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const void* __restrict__ dy, int dys, const void* __restrict__ x,
                                                              int xs, Shape2 s, int bxl, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, int relu,
-                                                             float* __restrict__ ws, int Cpad) {
+                                                             const float* __restrict__ beta, float* __restrict__ ws, int Cpad) {
     constexpr int V = T::kVec;
     int cv; long p, ps;
     thread_coords(bxl, cv, p, ps, s);
@@ -195,75 +249,101 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const void* __restr
     for (int e = 0; e < V; ++e) a[e] = b[e] = 0.f;
     if (cv < s.CV) {
         float mu[V], is[V], g[V], be[V];
+        const float* gp = gamma ? gamma : mean;     // unconditional loads + select (see affine_act_kernel)
+        const float* bp = beta ? beta : mean;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             mu[e] = mean[cv * V + e]; is[e] = invstd[cv * V + e];
-            g[e] = gamma ? gamma[cv * V + e] : 1.f; be[e] = beta ? beta[cv * V + e] : 0.f;
+            const float gv = gp[cv * V + e], bv = bp[cv * V + e];
+            g[e] = gamma ? gv : 1.f; be[e] = beta ? bv : 0.f;
         }
-        for (; p < s.M; p += ps) {
+        const char* xb = (const char*)x + (size_t)cv * 16;
+        const char* db = (const char*)dy + (size_t)cv * 16;
+        const size_t xst = (size_t)xs * T::kBytes, dst = (size_t)dys * T::kBytes;
+        auto one = [&](const u32x4_t& vx, const u32x4_t& vd) {
             float fx[V], fd[V];
-            ldv<T>(x, (size_t)p * xs + cv * V, fx);
-            ldv<T>(dy, (size_t)p * dys + cv * V, fd);
+            T::unpack(vx, fx);
+            T::unpack(vd, fd);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const float xh = (fx[e] - mu[e]) * is[e];
                 float d = fd[e];
-                if (relu && !(xh * g[e] + be[e] > 0.f)) d = 0.f;
+                if (RELU) d = (xh * g[e] + be[e] > 0.f) ? d : 0.f;
                 a[e] += d; b[e] += d * xh;
             }
-        }
-    }
-    __shared__ float red[256][2 * 8 + 1];
+        };
+        for (; p + (U - 1) * ps < s.M; p += U * ps) {
+            u32x4_t vx[U], vd[U];
 #pragma unroll
-    for (int e = 0; e < V; ++e) { red[threadIdx.x][e] = a[e]; red[threadIdx.x][8 + e] = b[e]; }
-    __syncthreads();
-    const int bx = 1 << bxl, by = 256 >> bxl;
-    if (threadIdx.x < bx && cv < s.CV) {
-        for (int e = 0; e < V; ++e) {
-            float sa = 0.f, sb = 0.f;
-            for (int t = 0; t < by; ++t) { sa += red[t * bx + threadIdx.x][e]; sb += red[t * bx + threadIdx.x][8 + e]; }
-            ws[((size_t)blockIdx.x * 2 + 0) * Cpad + cv * V + e] = sa;
-            ws[((size_t)blockIdx.x * 2 + 1) * Cpad + cv * V + e] = sb;
+            for (int u = 0; u < U; ++u) { vx[u] = ld16(xb, p + u * ps, xst); vd[u] = ld16(db, p + u * ps, dst); }
+        __builtin_amdgcn_sched_barrier(0);    // keep the whole batch of loads in front of their first use
+#pragma unroll
+            for (int u = 0; u < U; ++u) one(vx[u], vd[u]);
         }
+        for (; p < s.M; p += ps) one(ld16(xb, p, xst), ld16(db, p, dst));
     }
+    block_partials_out<V>(a, b, bxl, cv, s.CV, ws, Cpad);
 }
 
-template <typename T>
+template <typename T, int U, bool RELU, bool ACC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ dy, int dys, const void* __restrict__ x,
                                                            int xs, void* __restrict__ dx, int dxs, Shape2 s, int bxl,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           int relu, const float* __restrict__ sums, int C, int use_batch,
-                                                           int accumulate) {
+                                                           const float* __restrict__ sums, int C, int use_batch) {
     constexpr int V = T::kVec;
     int cv; long p, ps;
     thread_coords(bxl, cv, p, ps, s);
     if (cv >= s.CV) return;
     float mu[V], is[V], g[V], be[V], k0[V], k1[V];
     const float invM = 1.f / (float)s.M;
+    const float* gp = gamma ? gamma : mean;     // unconditional loads + select (see affine_act_kernel)
+    const float* bp = beta ? beta : mean;
+    const float* s0 = use_batch ? sums : mean;
+    const float* s1 = use_batch ? sums + C : mean;
 #pragma unroll
     for (int e = 0; e < V; ++e) {
         const int c = cv * V + e;
         mu[e] = mean[c]; is[e] = invstd[c];
-        g[e] = gamma ? gamma[c] : 1.f; be[e] = beta ? beta[c] : 0.f;
-        k0[e] = use_batch ? sums[c] * invM : 0.f;
-        k1[e] = use_batch ? sums[C + c] * invM : 0.f;
+        const float gv = gp[c], bv = bp[c], s0v = s0[c], s1v = s1[c];
+        g[e] = gamma ? gv : 1.f; be[e] = beta ? bv : 0.f;
+        k0[e] = use_batch ? s0v * invM : 0.f;
+        k1[e] = use_batch ? s1v * invM : 0.f;
     }
-#pragma unroll 2
-    for (; p < s.M; p += ps) {
+    const char* xb = (const char*)x + (size_t)cv * 16;
+    const char* db = (const char*)dy + (size_t)cv * 16;
+    char* ob = (char*)dx + (size_t)cv * 16;
+    const size_t xst = (size_t)xs * T::kBytes, dst = (size_t)dys * T::kBytes, ost = (size_t)dxs * T::kBytes;
+    auto one = [&](const u32x4_t& vx, const u32x4_t& vd, const u32x4_t& vo, long q) {
         float fx[V], fd[V], o[V];
-        ldv<T>(x, (size_t)p * xs + cv * V, fx);
-        ldv<T>(dy, (size_t)p * dys + cv * V, fd);
-        if (accumulate) ldv<T>(dx, (size_t)p * dxs + cv * V, o);
+        T::unpack(vx, fx);
+        T::unpack(vd, fd);
+        if (ACC) T::unpack(vo, o);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             const float xh = (fx[e] - mu[e]) * is[e];
             float d = fd[e];
-            if (relu && !(xh * g[e] + be[e] > 0.f)) d = 0.f;
+            if (RELU) d = (xh * g[e] + be[e] > 0.f) ? d : 0.f;
             const float r = g[e] * is[e] * (d - k0[e] - xh * k1[e]);
-            o[e] = accumulate ? o[e] + r : r;
+            o[e] = ACC ? o[e] + r : r;
         }
-        stv<T>(dx, (size_t)p * dxs + cv * V, o);
+        st16(ob, q, ost, T::pack(o));
+    };
+    for (; p + (U - 1) * ps < s.M; p += U * ps) {
+        u32x4_t vx[U], vd[U], vo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            vx[u] = ld16(xb, p + u * ps, xst);
+            vd[u] = ld16(db, p + u * ps, dst);
+            if (ACC) vo[u] = ld16(ob, p + u * ps, ost); else vo[u] = vx[u];
+        }
+        __builtin_amdgcn_sched_barrier(0);    // keep the whole batch of loads in front of their first use
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(vx[u], vd[u], vo[u], p + u * ps);
+    }
+    for (; p < s.M; p += ps) {
+        const u32x4_t vx = ld16(xb, p, xst);
+        one(vx, ld16(db, p, dst), ACC ? ld16(ob, p, ost) : vx, p);
     }
 }
 
@@ -289,25 +369,39 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const void* __restrict__ d
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void act_bwd_vec_kernel(const void* __restrict__ dy, int dys, const void* __restrict__ y, int ys,
-                                                          void* __restrict__ dz, int dzs, Shape2 s, int bxl, int act) {
+// dz may alias dy (the decoder applies the activation derivative in place): no __restrict__ on those two
+template <typename T, int U>
+__global__ __launch_bounds__(256) void act_bwd_vec_kernel(const void* dy, int dys, const void* __restrict__ y, int ys,
+                                                          void* dz, int dzs, Shape2 s, int bxl, int act) {
     constexpr int V = T::kVec;
     int cv; long p, ps;
     thread_coords(bxl, cv, p, ps, s);
     if (cv >= s.CV) return;
-#pragma unroll 2
-    for (; p < s.M; p += ps) {
+    const bool elu = act == BTS_ACT_ELU;
+    const char* db = (const char*)dy + (size_t)cv * 16;
+    const char* yb = (const char*)y + (size_t)cv * 16;
+    char* zb = (char*)dz + (size_t)cv * 16;
+    const size_t dst = (size_t)dys * T::kBytes, yst = (size_t)ys * T::kBytes, zst = (size_t)dzs * T::kBytes;
+    auto one = [&](const u32x4_t& vd, const u32x4_t& vy, long q) {
         float g[V], v[V];
-        ldv<T>(dy, (size_t)p * dys + cv * V, g);
-        ldv<T>(y, (size_t)p * ys + cv * V, v);
+        T::unpack(vd, g);
+        T::unpack(vy, v);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            if (act == BTS_ACT_ELU) g[e] = g[e] * (v[e] > 0.f ? 1.f : v[e] + 1.f);
-            else if (act == BTS_ACT_RELU) g[e] = v[e] > 0.f ? g[e] : 0.f;
+            const float neg = elu ? g[e] * (v[e] + 1.f) : 0.f;     // ELU'(z) = y + 1 for z <= 0 ; ReLU' = 0
+            g[e] = v[e] > 0.f ? g[e] : neg;
         }
-        stv<T>(dz, (size_t)p * dzs + cv * V, g);
+        st16(zb, q, zst, T::pack(g));
+    };
+    for (; p + (U - 1) * ps < s.M; p += U * ps) {
+        u32x4_t vd[U], vy[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { vd[u] = ld16(db, p + u * ps, dst); vy[u] = ld16(yb, p + u * ps, yst); }
+        __builtin_amdgcn_sched_barrier(0);    // keep the whole batch of loads in front of their first use
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(vd[u], vy[u], p + u * ps);
     }
+    for (; p < s.M; p += ps) one(ld16(db, p, dst), ld16(yb, p, yst), p);
 }
 
 template <typename TX, typename TY>
@@ -368,6 +462,68 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restric
     }
 }
 
+// bf16 -> bf16 layout conversions with 16-byte global accesses on both sides: a 64-channel x 64-pixel tile goes through
+// LDS as packed bf16 pairs (row pitch 33 dwords).  Need HW % 8 == 0 and C % 8 == 0 (every 8-element group is then
+// entirely inside or outside the tensor) and 16-byte aligned rows; the 32x32 scalar kernels above serve everything else.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_wide_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
+                                                                int ds, int C, int HW) {
+    __shared__ uint32_t tile[64][33];      // [channel][pixel pair]
+    const int n = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+    const int t = threadIdx.x, r = t >> 3, sg = t & 7;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {          // read: 8 lanes x 16 B = the 64 pixels of one channel row
+        const int c = c0 + r + 32 * h, p = p0 + 8 * sg;
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (c < C && p < HW) v = *(const u32x4_t*)(src + ((size_t)n * C + c) * HW + p);
+        uint32_t* row = &tile[r + 32 * h][4 * sg];
+        row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {          // write: 8 lanes x 16 B = the 64 channels of one pixel
+        const int pp = r + 32 * h, c = c0 + 8 * sg, p = p0 + pp;
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = tile[8 * sg + j][pp >> 1];
+        const int sh = (pp & 1) * 16;
+        u32x4_t o;
+        o.x = ((w[0] >> sh) & 0xffffu) | ((w[1] >> sh) << 16);
+        o.y = ((w[2] >> sh) & 0xffffu) | ((w[3] >> sh) << 16);
+        o.z = ((w[4] >> sh) & 0xffffu) | ((w[5] >> sh) << 16);
+        o.w = ((w[6] >> sh) & 0xffffu) | ((w[7] >> sh) << 16);
+        if (c < C && p < HW) *(u32x4_t*)(dst + ((size_t)n * HW + p) * ds + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_wide_kernel(const uint16_t* __restrict__ src, int ss,
+                                                                uint16_t* __restrict__ dst, int C, int HW) {
+    typedef uint16_t __attribute__((may_alias)) u16a_t;
+    __shared__ uint32_t tile[64][33];      // [channel][pixel pair]
+    u16a_t* t16 = (u16a_t*)&tile[0][0];    // halfword view, pitch 66
+    const int n = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+    const int t = threadIdx.x, r = t >> 3, sg = t & 7;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {          // read: 8 lanes x 16 B = the 64 channels of one pixel
+        const int pp = r + 32 * h, c = c0 + 8 * sg, p = p0 + pp;
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (c < C && p < HW) v = *(const u32x4_t*)(src + ((size_t)n * HW + p) * ss + c);
+        u16a_t* col = t16 + (8 * sg) * 66 + pp;
+        col[0 * 66] = (uint16_t)v.x; col[1 * 66] = (uint16_t)(v.x >> 16);
+        col[2 * 66] = (uint16_t)v.y; col[3 * 66] = (uint16_t)(v.y >> 16);
+        col[4 * 66] = (uint16_t)v.z; col[5 * 66] = (uint16_t)(v.z >> 16);
+        col[6 * 66] = (uint16_t)v.w; col[7 * 66] = (uint16_t)(v.w >> 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {          // write: 8 lanes x 16 B = the 64 pixels of one channel row
+        const int c = c0 + r + 32 * h, p = p0 + 8 * sg;
+        const uint32_t* row = &tile[r + 32 * h][4 * sg];
+        u32x4_t o;
+        o.x = row[0]; o.y = row[1]; o.z = row[2]; o.w = row[3];
+        if (c < C && p < HW) *(u32x4_t*)(dst + ((size_t)n * C + c) * HW + p) = o;
+    }
+}
+
 // ---- fused multi-tensor AdamW --------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adamw_kernel(float* const* __restrict__ params, float* const* __restrict__ grads,
                                                     float* const* __restrict__ m1, float* const* __restrict__ m2,
@@ -419,7 +575,7 @@ static int flat_blocks(long total) {
 
 static int bn_parts(long M, int CV) {
     int bxl; dim3 g;
-    pick_grid(M, CV, bxl, g, 512);
+    pick_grid(M, CV, bxl, g, g_part_blocks);
     return (int)g.x;
 }
 extern "C" long bts_bn_stats_workspace_bytes(long M, int C) {
@@ -428,20 +584,27 @@ extern "C" long bts_bn_stats_workspace_bytes(long M, int C) {
     return (long)(p4 > p8 ? p4 : p8) * 2 * Cpad * sizeof(float) + 64;
 }
 
+static void launch_stats_final(const float* ws, int nparts, int C, int Cpad, double M, int mode, float* out0, float* out1,
+                               hipStream_t st) {
+    if (g_final_lanes == 32)
+        hipLaunchKernelGGL(bn_stats_final_kernel<32>, dim3(ceil_div(C, 32)), dim3(1024), 0, st, ws, nparts, C, Cpad, M, mode, out0, out1);
+    else
+        hipLaunchKernelGGL(bn_stats_final_kernel<8>, dim3(ceil_div(C, 32)), dim3(256), 0, st, ws, nparts, C, Cpad, M, mode, out0, out1);
+}
+
 extern "C" int bts_bn_stats(const void* x, int dtype, int stride, long M, int C, void* workspace, float* mean, float* var,
                             bts_stream_t stream) {
     BTS_CHECK_ARG(x && workspace && mean && var && M > 0 && C > 0);
     BTS_CHECK_ARG((dtype == BTS_F32 || dtype == BTS_BF16) && vec_ok(dtype, C, stride, x));
     const int V = dtype == BTS_F32 ? 4 : 8, CV = C / V, Cpad = (C + 7) / 8 * 8;
     int bxl; dim3 grid;
-    pick_grid(M, CV, bxl, grid, 512);
+    pick_grid(M, CV, bxl, grid, g_part_blocks);
     Shape2 s{M, CV};
     hipStream_t st = (hipStream_t)stream;
-#define L_(TT, dummy) hipLaunchKernelGGL(bn_stats_partial_kernel<TT>, grid, dim3(256), 0, st, x, stride, s, bxl, (float*)workspace, Cpad)
-    DISPATCH_T(dtype, L_, 0);
+#define L_(TT, UU) hipLaunchKernelGGL((bn_stats_partial_kernel<TT, UU>), grid, dim3(256), 0, st, x, stride, s, bxl, (float*)workspace, Cpad)
+    if (g_unroll4) DISPATCH_T(dtype, L_, 4); else DISPATCH_T(dtype, L_, 2);
 #undef L_
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, st, (const float*)workspace, (int)grid.x, C,
-                       Cpad, (double)M, 0, mean, var);
+    launch_stats_final((const float*)workspace, (int)grid.x, C, Cpad, (double)M, 0, mean, var, st);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }
@@ -467,8 +630,11 @@ extern "C" int bts_affine_act(const void* x, int x_dtype, int x_stride, void* y,
     pick_grid(M, CV, bxl, grid);
     Shape2 s{M, CV};
     hipStream_t st = (hipStream_t)stream;
-    if (x_dtype == BTS_F32) hipLaunchKernelGGL((affine_act_kernel<F32, F32>), grid, dim3(256), 0, st, x, x_stride, y, y_stride, s, bxl, scale, shift, act);
-    else hipLaunchKernelGGL((affine_act_kernel<BF16, BF16>), grid, dim3(256), 0, st, x, x_stride, y, y_stride, s, bxl, scale, shift, act);
+#define L_(TT, UU, TB) hipLaunchKernelGGL((affine_act_kernel<TT, UU, TB>), grid, dim3(256), 0, st, x, x_stride, y, y_stride, s, bxl, scale, shift, act)
+#define LU_(TT, TB) do { if (g_unroll4) L_(TT, 4, TB); else L_(TT, 2, TB); } while (0)
+    if (scale && shift) DISPATCH_T(x_dtype, LU_, true); else DISPATCH_T(x_dtype, LU_, false);
+#undef LU_
+#undef L_
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }
@@ -480,14 +646,15 @@ extern "C" int bts_bn_bwd_reduce(const void* dy, int dy_stride, const void* x, i
     BTS_CHECK_ARG((dtype == BTS_F32 || dtype == BTS_BF16) && vec_ok(dtype, C, x_stride, x) && vec_ok(dtype, C, dy_stride, dy));
     const int V = dtype == BTS_F32 ? 4 : 8, CV = C / V, Cpad = (C + 7) / 8 * 8;
     int bxl; dim3 grid;
-    pick_grid(M, CV, bxl, grid, 512);
+    pick_grid(M, CV, bxl, grid, g_part_blocks);
     Shape2 s{M, CV};
     hipStream_t st = (hipStream_t)stream;
-#define L_(TT, dummy) hipLaunchKernelGGL(bn_bwd_partial_kernel<TT>, grid, dim3(256), 0, st, dy, dy_stride, x, x_stride, s, bxl, mean, invstd, gamma, beta, relu, (float*)workspace, Cpad)
-    DISPATCH_T(dtype, L_, 0);
+#define L_(TT, UU, RR) hipLaunchKernelGGL((bn_bwd_partial_kernel<TT, UU, RR>), grid, dim3(256), 0, st, dy, dy_stride, x, x_stride, s, bxl, mean, invstd, gamma, beta, (float*)workspace, Cpad)
+#define LU_(TT, RR) do { if (g_unroll4) L_(TT, 4, RR); else L_(TT, 2, RR); } while (0)
+    if (relu) DISPATCH_T(dtype, LU_, true); else DISPATCH_T(dtype, LU_, false);
+#undef LU_
 #undef L_
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, st, (const float*)workspace, (int)grid.x, C,
-                       Cpad, (double)M, 1, sums, sums + C);
+    launch_stats_final((const float*)workspace, (int)grid.x, C, Cpad, (double)M, 1, sums, sums + C, st);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }
@@ -503,8 +670,11 @@ extern "C" int bts_bn_bwd_apply(const void* dy, int dy_stride, const void* x, in
     pick_grid(M, CV, bxl, grid);
     Shape2 s{M, CV};
     hipStream_t st = (hipStream_t)stream;
-#define L_(TT, dummy) hipLaunchKernelGGL(bn_bwd_apply_kernel<TT>, grid, dim3(256), 0, st, dy, dy_stride, x, x_stride, dx, dx_stride, s, bxl, mean, invstd, gamma, beta, relu, sums, C, use_batch_stats, accumulate)
-    DISPATCH_T(dtype, L_, 0);
+#define L_(TT, UU, RR, AA) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, UU, RR, AA>), grid, dim3(256), 0, st, dy, dy_stride, x, x_stride, dx, dx_stride, s, bxl, mean, invstd, gamma, beta, sums, C, use_batch_stats)
+#define LU_(TT, RR, AA) do { if (g_unroll4) L_(TT, 4, RR, AA); else L_(TT, 2, RR, AA); } while (0)
+    if (relu) { if (accumulate) DISPATCH_T(dtype, LU_, true, true); else DISPATCH_T(dtype, LU_, true, false); }
+    else      { if (accumulate) DISPATCH_T(dtype, LU_, false, true); else DISPATCH_T(dtype, LU_, false, false); }
+#undef LU_
 #undef L_
     BTS_LAUNCH_CHECK();
     return BTS_OK;
@@ -523,8 +693,8 @@ extern "C" int bts_act_bwd(const void* dy, int dy_dtype, int dy_stride, const vo
         int bxl; dim3 grid;
         pick_grid(M, CV, bxl, grid);
         Shape2 s{M, CV};
-#define L_(TT, dummy) hipLaunchKernelGGL(act_bwd_vec_kernel<TT>, grid, dim3(256), 0, st, dy, dy_stride, y, y_stride, dz, dz_stride, s, bxl, act)
-        DISPATCH_T(dy_dtype, L_, 0);
+#define L_(TT, UU) hipLaunchKernelGGL((act_bwd_vec_kernel<TT, UU>), grid, dim3(256), 0, st, dy, dy_stride, y, y_stride, dz, dz_stride, s, bxl, act)
+        if (g_unroll4) DISPATCH_T(dy_dtype, L_, 4); else DISPATCH_T(dy_dtype, L_, 2);
 #undef L_
     } else {
         const int nb = flat_blocks(M * C);
@@ -571,8 +741,15 @@ extern "C" int bts_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int d
     BTS_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && dst_stride >= C);
     BTS_CHECK_ARG((dst_dtype == BTS_F32 || dst_dtype == BTS_BF16) && (src_dtype == BTS_F32 || src_dtype == BTS_BF16));
     const int HW = H * W;
-    dim3 grid(ceil_div(HW, 32), ceil_div(C, 32), N);
     hipStream_t st = (hipStream_t)stream;
+    if (g_wide_transpose && src_dtype == BTS_BF16 && dst_dtype == BTS_BF16 && !relu && HW % 8 == 0 && C % 8 == 0 &&
+        dst_stride % 8 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        hipLaunchKernelGGL(nchw_to_nhwc_wide_kernel, dim3(ceil_div(HW, 64), ceil_div(C, 64), N), dim3(256), 0, st,
+                           (const uint16_t*)src, (uint16_t*)dst, dst_stride, C, HW);
+        BTS_LAUNCH_CHECK();
+        return BTS_OK;
+    }
+    dim3 grid(ceil_div(HW, 32), ceil_div(C, 32), N);
 #define L_(A, B) hipLaunchKernelGGL((nchw_to_nhwc_kernel<A, B>), grid, dim3(256), 0, st, src, dst, dst_stride, C, HW, relu)
     if (src_dtype == BTS_F32) { if (dst_dtype == BTS_F32) L_(F32, F32); else L_(F32, BF16); }
     else { if (dst_dtype == BTS_F32) L_(BF16, F32); else L_(BF16, BF16); }
@@ -586,8 +763,15 @@ extern "C" int bts_nhwc_to_nchw(const void* src, int src_dtype, int src_stride, 
     BTS_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && src_stride >= C);
     BTS_CHECK_ARG((src_dtype == BTS_F32 || src_dtype == BTS_BF16) && (dst_dtype == BTS_F32 || dst_dtype == BTS_BF16));
     const int HW = H * W;
-    dim3 grid(ceil_div(HW, 32), ceil_div(C, 32), N);
     hipStream_t st = (hipStream_t)stream;
+    if (g_wide_transpose && src_dtype == BTS_BF16 && dst_dtype == BTS_BF16 && !relu_src && HW % 8 == 0 && C % 8 == 0 &&
+        src_stride % 8 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        hipLaunchKernelGGL(nhwc_to_nchw_wide_kernel, dim3(ceil_div(HW, 64), ceil_div(C, 64), N), dim3(256), 0, st,
+                           (const uint16_t*)src, src_stride, (uint16_t*)dst, C, HW);
+        BTS_LAUNCH_CHECK();
+        return BTS_OK;
+    }
+    dim3 grid(ceil_div(HW, 32), ceil_div(C, 32), N);
 #define L_(A, B) hipLaunchKernelGGL((nhwc_to_nchw_kernel<A, B>), grid, dim3(256), 0, st, src, src_stride, dst, relu_src, C, HW)
     if (src_dtype == BTS_F32) { if (dst_dtype == BTS_F32) L_(F32, F32); else L_(F32, BF16); }
     else { if (dst_dtype == BTS_F32) L_(BF16, F32); else L_(BF16, BF16); }

@@ -218,12 +218,15 @@ def test_conv_epilogues():
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("relu", [False, True])
-def test_batchnorm_train_fwd_bwd(dt, relu):
-    """bn_stats + bn_prepare + affine_act and the two-pass backward vs F.batch_norm autograd (CPU f32)."""
+@pytest.mark.parametrize("shape", [(3, 40, 9, 11), (2, 72, 97, 103)], ids=["small", "multi_iter"])
+def test_batchnorm_train_fwd_bwd(dt, relu, shape):
+    """bn_stats + bn_prepare + affine_act and the two-pass backward vs F.batch_norm autograd (CPU f32).  `multi_iter`:
+    ~20 k pixels on 9 / 18 channel vectors, so every thread of the streaming kernels walks several pixels (the batched
+    4-iteration main loop and its tail), with a pixel count that is not a multiple of anything."""
     from bts_amd import ops
     from bts_amd._lib import ACT_NONE, ACT_RELU
     gen = torch.Generator().manual_seed(7)
-    N, C, H, W = 3, 40, 9, 11
+    N, C, H, W = shape
     v = 4 if dt == torch.float32 else 8
     tol = 1e-4 if dt == torch.float32 else 2e-2
     x = torch.randn(N, C, H, W, generator=gen) * 1.5 + 0.3
@@ -251,6 +254,44 @@ def test_batchnorm_train_fwd_bwd(dt, relu):
     db, dg = ops.bn_bwd(_nhwc(gy, dt, v), xt, mean, invstd, g.to(DEV), b.to(DEV), relu, dx, False)
     assert rel(dx.float().permute(0, 3, 1, 2), xr.grad) < tol * 5
     assert rel(dg, gr.grad) < tol * 5 and rel(db, br.grad) < tol * 5
+    # accumulate form (a tensor that feeds several BatchNorms of the dense ASPP): dx += ..., bit-identical sums
+    base = torch.randn(dx.shape, generator=gen).to(dt).to(DEV)
+    acc = base.clone()
+    db2, dg2 = ops.bn_bwd(_nhwc(gy, dt, v), xt, mean, invstd, g.to(DEV), b.to(DEV), relu, acc, True)
+    assert torch.equal(db2, db) and torch.equal(dg2, dg)
+    assert rel(acc.float() - base.float(), dx.float()) < (1e-5 if dt == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_act_bwd_streaming(dt):
+    """ELU' / ReLU' through the vector kernel, out of place and in place (the decoder's form), several pixels per thread."""
+    from bts_amd import ops
+    from bts_amd._lib import ACT_ELU, ACT_RELU
+    gen = torch.Generator().manual_seed(11)
+    N, H, W, C = 2, 97, 103, 72
+    y = (torch.randn(N, H, W, C, generator=gen)).to(dt).to(DEV)
+    gy = torch.randn(N, H, W, C, generator=gen).to(dt).to(DEV)
+    for act in (ACT_ELU, ACT_RELU):
+        yf, gf = y.float(), gy.float()
+        ref = (gf * torch.where(yf > 0, torch.ones_like(yf), yf + 1.0)) if act == ACT_ELU else torch.where(yf > 0, gf, torch.zeros_like(gf))
+        ref = ref.to(dt)
+        out = ops.act_bwd(gy, y, act)
+        assert torch.equal(out, ref)
+        g2 = gy.clone()
+        ops.act_bwd(g2, y, act, out=g2)
+        assert torch.equal(g2, ref)
+
+
+def test_layout_wide_bf16_ragged_tiles():
+    """bf16 -> bf16 conversions on the 64x64-tile kernels (H*W % 8 == 0, C % 8 == 0): 7 full pixel tiles + 8 pixels, 3 full
+    channel tiles + 8 channels, padded NHWC pitch; exact both ways, pad channels untouched."""
+    from bts_amd import ops
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 200, 19, 24, generator=gen).to(torch.bfloat16).to(DEV)
+    t = ops.nchw_to_nhwc(x, torch.bfloat16, c_pad=208)
+    assert torch.equal(t[..., :200].permute(0, 3, 1, 2), x) and t[..., 200:].abs().max().item() == 0
+    back = ops.nhwc_to_nchw(t, 200, out_dtype=torch.bfloat16)
+    assert torch.equal(back, x)
 
 
 def test_layout_roundtrip_and_pack_maps():
