@@ -1,0 +1,30 @@
+"""The stand-alone GPU probes under tools/probes/ compile the PRODUCT source (they #include bts_amd/csrc/*.hip with its
+launch-shape constants turned into variables), so they rot the moment a kernel signature changes.  Cross-compiling them
+for gfx950 needs no GPU."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+@pytest.mark.parametrize("probe", ["ew_probe.hip", "tr_probe.hip"])
+def test_probe_compiles_against_product_source(tmp_path, probe):
+    hipcc = _hipcc()
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    out = tmp_path / probe.replace(".hip", "")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value",
+           os.path.join(ROOT, "tools", "probes", probe), "-o", str(out)]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out.exists() and out.stat().st_size > 0
