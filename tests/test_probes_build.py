@@ -17,7 +17,7 @@ def _hipcc():
     return None
 
 
-@pytest.mark.parametrize("probe", ["ew_probe.hip", "tr_probe.hip"])
+@pytest.mark.parametrize("probe", ["ew_probe.hip", "tr_probe.hip", "wgrad_tile_probe.hip"])
 def test_probe_compiles_against_product_source(tmp_path, probe):
     hipcc = _hipcc()
     if hipcc is None:
