@@ -187,37 +187,37 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_tn_tr(const GemmP a) {
 
     // ---- epilogue -------------------------------------------------------------------------------------------------------
     // Unsplit tiles add into C with plain read-modify-writes (deterministic).  Written element by element -- as the product
-    // kernel has it -- hipcc emits load, s_waitcnt vmcnt(0), store per element (it cannot prove the addresses distinct): 64-128
-    // serialised memory round trips per thread, tens of microseconds per workgroup.  Here the 16 loads of a 32 x 32 block are
-    // issued together, then the 16 stores.
+    // kernel has it -- hipcc emits load, s_waitcnt vmcnt(0), store per element (it cannot prove the addresses distinct, and on
+    // gfx9 vmcnt counts the stores too): 64-128 serialised memory round trips per thread, tens of microseconds per workgroup.
+    // For a 32-row block that lies entirely inside M (wave-uniform test) the 16 loads are issued together, pinned in front of the
+    // 16 stores, and nothing in between is predicated: one wait per block.  (tools/r3_prep/0001 is this change for the product.)
     const int frow = lane & 31, fk = lane >> 5;
     const bool single = gridDim.y == 1;
 #pragma unroll
     for (int j = 0; j < FB; ++j) {
         const int col = nt * TN + (wc * FB + j) * 32 + frow;
-        if (col >= a.N) continue;
+        const bool col_ok = col < a.N;
 #pragma unroll
         for (int i = 0; i < FA; ++i) {
-            const int row0 = mt * TM + (wr * FA + i) * 32 + 4 * fk;
-            float* p0 = a.C + (size_t)row0 * a.ldc + col;
-            if (single) {
-                float old[16];
+            const int rb = mt * TM + (wr * FA + i) * 32;
+            const int row0 = rb + 4 * fk;
+            float* p0 = a.C + (size_t)row0 * a.ldc + (col_ok ? col : 0);
+            if (single && rb + 32 <= a.M) {
+                if (col_ok) {
+                    float old[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
-                    old[r] = row0 + dr < a.M ? p0[(size_t)dr * a.ldc] : 0.f;
+                    for (int r = 0; r < 16; ++r) old[r] = p0[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldc];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p0[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldc] = old[r] + acc[i][j][r];
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            } else if (col_ok) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dr = (r & 3) + 8 * (r >> 2);
-                    if (row0 + dr < a.M) p0[(size_t)dr * a.ldc] = old[r] + acc[i][j][r];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
-                    if (row0 + dr < a.M) atomicAdd(p0 + (size_t)dr * a.ldc, acc[i][j][r]);
+                    if (row0 + dr >= a.M) continue;
+                    if (single) p0[(size_t)dr * a.ldc] += acc[i][j][r];
+                    else atomicAdd(p0 + (size_t)dr * a.ldc, acc[i][j][r]);
                 }
             }
         }
