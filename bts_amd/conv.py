@@ -56,8 +56,18 @@ def _cdiv(a, b):
     return (a + b - 1) // b
 
 
+_CUS = []
+
+
+def _cu_count():
+    if not _CUS:
+        _CUS.append(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count if torch.cuda.is_available() else 256)
+    return _CUS[0]
+
+
 def _wide_pays(cout, n, hg, wg):
     """Mirrors launch_halo_wide()'s fill heuristic (csrc/conv_halo_wide.hip)."""
+    cus = _cu_count()
     mode = os.environ.get("BTS_CONV_WIDE", "1")[:1]
     if mode == "0":
         return False
@@ -66,8 +76,8 @@ def _wide_pays(cout, n, hg, wg):
     ntiles = _cdiv(wg, 32) * _cdiv(hg, 8) * n
     nco = _cdiv(cout, 128)
     wgs = ntiles * nco
-    rounds = _cdiv(wgs, 256)
-    fill = (hg * wg * n / (ntiles * 256.0)) * (cout / (nco * 128.0)) * (wgs / (rounds * 256.0))
+    rounds = _cdiv(wgs, cus)
+    fill = (hg * wg * n / (ntiles * 256.0)) * (cout / (nco * 128.0)) * (wgs / float(rounds * cus))
     return fill >= 0.70
 
 

@@ -106,6 +106,20 @@ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
         if (e__ != hipSuccess) return BTS_ERR_LAUNCH;            \
     } while (0)
 
+// Compute units of the current device (256 on MI355X), queried once per device: fill heuristics and persistent grids use this
+// instead of a literal.  Idempotent cache like DynLdsCache below; not a stream operation.
+static inline int bts_cu_count() {
+    static std::atomic<int> cus[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 256;
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 // Dynamic-LDS opt-in of a kernel (needed above 48 KiB), remembered per device so it is a host call only the first
 // time a (kernel, device) pair needs more than it already has.  The cache is idempotent (racing threads set the same
 // attribute) and is not a stream operation, so it never lands inside a graph capture after the warm-up pass.

@@ -46,6 +46,14 @@ struct ConvK {
     int kmajor;    // conv_igemm_dma K order: 1 = channel chunk outer, taps inner (needs KV % 8 == 0); 0 = tap outer
 };
 
+// The strength-reduced address paths multiply (pixel index) x (pixel stride in bytes) in 32 bits: a launcher that uses them
+// must refuse inputs of 4 GiB or more per segment (the generic 64-bit path takes those).
+static inline bool segs_fit_u32(const ConvK& k) {
+    for (int s = 0; s < k.nseg; ++s)
+        if ((unsigned long long)k.N * k.Hx * k.Wx * k.seg_sb[s] >= (1ull << 32)) return false;
+    return true;
+}
+
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 __device__ __forceinline__ int remap_xcd(int b, int nb) {
@@ -149,6 +157,43 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16_t (&acc)[TM
         if (a.out_scale_n) sc *= a.out_scale_n[n];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            // accumulate form of a 32-channel block that lies entirely inside Cout (wave-uniform test): the four old vectors are
+            // fetched together, pinned in front of the stores, and nothing in between is predicated.  In the general loop below
+            // hipcc serialises load / s_waitcnt vmcnt(0) / add / store per vector (it cannot prove the addresses distinct, and
+            // every predicated block waits for the previous store: on gfx9 vmcnt counts stores too).
+            const int cb = co_tile * BM + (wr * TM + i) * 32;
+            if (a.accumulate && a.vec_store && cb + 32 <= a.Cout) {
+                const size_t o0 = opix * a.y_stride + cb + 4 * fk;
+                f32x4_t oldv[4];
+                if (a.y_f32) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) oldv[q] = *(const f32x4_t*)((const float*)a.y + o0 + 8 * q);
+                } else {
+                    u32x2_t h[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) h[q] = *(const u32x2_t*)((const uint16_t*)a.y + o0 + 8 * q);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        oldv[q] = f32x4_t{__uint_as_float(h[q].x << 16), __uint_as_float(h[q].x & 0xffff0000u),
+                                          __uint_as_float(h[q].y << 16), __uint_as_float(h[q].y & 0xffff0000u)};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4_t t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float u = acc[i][j][4 * q + e];
+                        if (a.act == BTS_ACT_ELU) u = act_elu(u);
+                        else if (a.act == BTS_ACT_SIGMOID) u = act_sigmoid(u);
+                        else if (a.act == BTS_ACT_RELU) u = fmaxf(u, 0.f);
+                        t[e] = u * sc + oldv[q][e];
+                    }
+                    if (a.y_f32) *(f32x4_t*)((float*)a.y + o0 + 8 * q) = t;
+                    else *(u32x2_t*)((uint16_t*)a.y + o0 + 8 * q) = u32x2_t{pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
+                }
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int co = co_tile * BM + (wr * TM + i) * 32 + 8 * q + 4 * fk;

@@ -8,8 +8,8 @@
 // kernel does both for 128 output channels per workgroup:
 //
 //   * patch of the chunk: 340 pixel rows x 128 B, double-buffered across chunks (2 x 48 KiB);
-//   * weights: ONE tap of the chunk at a time, 128 co x 128 B = 16 KiB, through a 3-stage LDS ring filled by LDS-DMA two to
-//     three taps ahead (counted vmcnt, one raw s_barrier per tap);
+//   * weights: ONE tap of the chunk at a time, 128 co x 128 B = 16 KiB, through a 4-stage LDS ring filled by LDS-DMA three
+//     taps ahead (counted vmcnt, one raw s_barrier per tap);
 //   * per tap every wave (= one tile row of 32 pixels) issues 16 MFMAs: 4 co tiles x 4 k-steps, the B fragment of a k-step
 //     shared by the four co tiles;
 //   => staged bytes per tap: 16 KiB of weights + 1/9 of the patch = 21.4 KiB for 128 x 256 x 64 MAC: 96 MAC per staged byte,
@@ -36,7 +36,8 @@ constexpr int NCO = 4, BM = NCO * 32;                                 // 128 out
 constexpr int WPASS = BM / RP;                                        // 2 weight pieces per thread per tap
 constexpr int NWS = 4;                                                // weight ring stages (2 x 48 KiB + 4 x 16 KiB = all 160 KiB of LDS)
 constexpr int PBYTES = PR_PAD * 128, WBYTES = BM * 128;
-constexpr int LDS_BYTES = 2 * PBYTES + NWS * WBYTES;                  // 147456
+constexpr int LDS_BYTES = 2 * PBYTES + NWS * WBYTES;                  // 2 x 49152 + 4 x 16384 = 163840
+static_assert(LDS_BYTES <= 160 * 1024, "conv_halo_wide: patch double buffer + weight ring exceed the 160 KiB of a CU");
 
 __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
     using T = BF16;
@@ -166,8 +167,10 @@ __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
     // Order of DMA issue: P(0) W(0) W(1) W(2) | step j: W(j+3) [+ one piece of P(chunk+1) for taps 0..5].  LDS-DMA completes in
     // order, so "W(j+1) has landed" = at most the groups issued after it are outstanding (NY).  The barrier of step j
     //   RAW  publishes W(j+1) (every wave waited for its own pieces) before anyone reads it (second half of step j), and the
-    //        complete patch of chunk c+1 (pieces issued at taps 0..5 of chunk c, all older than the last wait of the chunk)
-    //        before the second half of step (c, 8) prefetches from it;
+    //        complete patch of chunk c+1 before the second half of step (c, 8) prefetches from it: its pieces are issued at
+    //        taps 0..5 of chunk c, each BEHIND that step's weights, so piece 5 is younger than W(j+1) of tap 8 -- the wait of
+    //        tap 8 therefore leaves only the weight groups of the two steps since outstanding (no patch piece): the data-gradient's
+    //        tap 0 is (+1, +1) and its bottom tile row reads patch rows 306..339, i.e. piece 5;
     //   WAR  stands behind every read of ring stage j%3 (k-steps 2,3 were waited for with lgkmcnt(0) just before it) and, at
     //        tap 8, behind the last reads of the chunk's patch buffer: the refills are issued after it.
     u32x4_t fbA[2], faA[2][NCO], fbB[2], faB[2][NCO];
@@ -223,8 +226,11 @@ __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
             });
             // groups younger than W(j+1) (issued NWS-1 steps ago, first in its step): the weights of the NWS-2 steps since, and
             // the patch pieces of the NWS-1 steps since (taps 0..5 carry one each, issued behind that step's weights)
-            constexpr int NY = (NWS - 2) * WPASS + (((tap + 8) % 9) < NPASS ? 1 : 0) + (((tap + 7) % 9) < NPASS ? 1 : 0) +
-                               (NWS >= 4 ? (((tap + 6) % 9) < NPASS ? 1 : 0) : 0);
+            // -- except at tap 8, whose barrier also publishes the whole next patch (see RAW above): no piece may be outstanding
+            constexpr int NY = tap == 8 ? (NWS - 2) * WPASS
+                                        : (NWS - 2) * WPASS + (((tap + 8) % 9) < NPASS ? 1 : 0) + (((tap + 7) % 9) < NPASS ? 1 : 0) +
+                                              (NWS >= 4 ? (((tap + 6) % 9) < NPASS ? 1 : 0) : 0);
+            static_assert(NPASS <= 6 && NWS == 4, "vmcnt bookkeeping above assumes pieces at taps 0..5 and a 4-stage ring");
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NY) : "memory");
             __builtin_amdgcn_s_barrier();
             // ---- second half: MFMAs of k-steps 2,3 (set B); prefetch of the next step's set A first, then the DMA issue
@@ -308,16 +314,17 @@ __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
 int launch_halo_wide(const ConvK& k0, hipStream_t st, int force) {
     ConvK k = k0;
     if (!(k.halo_ok && k.nphase == 1 && k.T == 9 && k.osc == 1 && k.Cout > 64)) return BTS_ERR_UNSUPPORTED;
+    if (!segs_fit_u32(k)) return BTS_ERR_UNSUPPORTED;                  // ppix * sb is a 32-bit product in the kernel
     k.n_co_tiles = ceil_div(k.Cout, BM);
     const int ntiles = ceil_div(k.Wg, TW) * ceil_div(k.Hg, TH) * k.N;
     if (!force) {
         // One 144 KiB workgroup per CU: the kernel only pays where its tiles cover the map, its co tiles are full and its
         // workgroups fill whole rounds of the 256 CUs.  Measured (r02m, same box, vs conv_igemm_dma): conv4 +21 %, conv3 +25 %,
         // daspp_conv +16 % at a combined fill of 0.82; conv5 (22x76 map: 72 % tile cover, 288 workgroups = 2 rounds) -33 % at 0.40.
-        const long wgs = (long)ntiles * k.n_co_tiles;
-        const long rounds = (wgs + 255) / 256;
+        const long wgs = (long)ntiles * k.n_co_tiles, cus = bts_cu_count();
+        const long rounds = (wgs + cus - 1) / cus;
         const double fill = ((double)k.Hg * k.Wg * k.N / ((double)ntiles * TH * TW)) * ((double)k.Cout / (k.n_co_tiles * BM)) *
-                            ((double)wgs / (rounds * 256.0));
+                            ((double)wgs / ((double)rounds * cus));
         if (fill < 0.70) return BTS_ERR_UNSUPPORTED;
     }
     static DynLdsCache lds_set;

@@ -197,6 +197,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(const ConvK a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // zero-page tail groups
 
     // ---- epilogue: dw[co][phase*T*K + col] += acc (f32 atomics only join the few pixel splits) --------------------------
+    // Unsplit tiles add with plain read-modify-writes (deterministic; dw arrives zeroed or holds an earlier contribution).
+    // Written element by element, hipcc emits load / s_waitcnt vmcnt(0) / store per element (it cannot prove the addresses
+    // distinct, and on gfx9 vmcnt also counts the stores): 64 serialised memory round trips per thread.  For a 32-channel block
+    // that lies entirely inside Cout (wave-uniform test, always true for the wide layers) the 16 loads are issued together,
+    // pinned in front of the 16 stores, and nothing in between is predicated, so there is one wait per block.
     const size_t row_len = (size_t)a.Ttot * a.Ktot;
     const int TK = a.T * a.Ktot;
     const int frow = lane & 31, fk = lane >> 5;
@@ -204,16 +209,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(const ConvK a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = col_tile * 128 + (wc * 2 + j) * 32 + frow;
-        if (col >= TK) continue;
+        const bool col_ok = col < TK;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            const int cb = co_tile * 128 + (wr * 2 + i) * 32;            // first channel of the block (wave-uniform)
+            const int co0 = cb + 4 * fk;
+            // columns beyond T*K re-read / re-write nothing: their lanes are switched off for the whole block
+            float* p0 = a.dw + (size_t)co0 * row_len + (size_t)phase * TK + (col_ok ? col : 0);
+            if (single && cb + 32 <= a.Cout) {
+                if (col_ok) {
+                    float old[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co_tile * 128 + (wr * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                if (co >= a.Cout) continue;
-                float* p = a.dw + (size_t)co * row_len + (size_t)phase * TK + col;
-                if (single) *p += acc[i][j][r];                 // dw arrives zeroed or holds an earlier contribution
-                else atomicAdd(p, acc[i][j][r]);
+                    for (int r = 0; r < 16; ++r) old[r] = p0[(size_t)((r & 3) + 8 * (r >> 2)) * row_len];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p0[(size_t)((r & 3) + 8 * (r >> 2)) * row_len] = old[r] + acc[i][j][r];
+                }
+            } else if (col_ok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (co0 + dr >= a.Cout) continue;
+                    if (single) p0[(size_t)dr * row_len] += acc[i][j][r];
+                    else atomicAdd(p0 + (size_t)dr * row_len, acc[i][j][r]);
+                }
             }
         }
     }
@@ -224,7 +243,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(const ConvK a) {
 int launch_wgrad_tr(const ConvK& k0, hipStream_t st) {
     ConvK k = k0;
     if (k.Cout <= 64) return BTS_ERR_UNSUPPORTED;
-    if ((long)k.N * k.Hy * k.Wy * k.dz_stride * 2 >= (1l << 32)) return BTS_ERR_UNSUPPORTED;
+    if ((long)k.N * k.Hy * k.Wy * k.dz_stride * 2 >= (1l << 32) || !segs_fit_u32(k)) return BTS_ERR_UNSUPPORTED;   // 32-bit byte offsets
     k.n_co_tiles = ceil_div(k.Cout, 128);
     k.n_col_tiles = ceil_div((long)k.T * k.Ktot, 128);
     k.nchunks = ceil_div(k.M, KC);
@@ -240,8 +259,6 @@ int launch_wgrad_tr(const ConvK& k0, hipStream_t st) {
     k.chunks_per_split = ceil_div(k.nchunks, splits);
     splits = ceil_div(k.nchunks, k.chunks_per_split);
     dim3 grid(k.n_co_tiles * k.n_col_tiles, splits, k.nphase);
-    static DynLdsCache attr;
-    (void)attr;
     hipLaunchKernelGGL(conv_wgrad_tr<2>, grid, dim3(256), 0, st, k);
     if (hipGetLastError() != hipSuccess) return BTS_ERR_LAUNCH;
     return BTS_OK;

@@ -12,6 +12,11 @@ host involvement.  The host only rewrites ``lr`` (the per-step poly schedule, bt
 and reads ``step`` back when a checkpoint is written (``state_dict``); ``load_state_dict`` restores the counter
 from the checkpoint's per-parameter ``step``, so resumed training continues with the right bias corrections.
 
+Restriction (documented, checked): the step count is ONE value per parameter group, where ``torch.optim.AdamW`` keeps one per
+parameter.  The two coincide whenever every parameter of a group receives a gradient on every step -- the case of
+bts_main.py, where frozen parameters are filtered out before the groups are built.  ``load_state_dict`` refuses a checkpoint
+whose per-parameter steps differ inside a group instead of silently rewriting them, and ``step(closure)`` is not supported.
+
 Gradients must keep their storage between steps (call ``zero_grad(set_to_none=False)``, the default here):
 the device pointer tables are rebuilt only when a pointer changes.
 """
@@ -40,12 +45,15 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def _group_step_from_state(self, g):
         """Step count recorded in the per-parameter state of group g (0 if the group has no state yet)."""
-        best = 0.0
+        seen = set()
         for p in g["params"]:
             st = self.state.get(p)
             if st and "step" in st:
-                best = max(best, float(st["step"]))
-        return best
+                seen.add(float(st["step"]))
+        if len(seen) > 1:
+            raise BtsAmdError("FusedAdamW keeps one step count per parameter group; this state has steps %s inside one group "
+                              "(load it with torch.optim.AdamW, or regroup the parameters)" % sorted(seen))
+        return seen.pop() if seen else 0.0
 
     def _rows(self):
         """The device rows, created on first use from the groups' hyper-parameters and recorded state."""
@@ -121,6 +129,8 @@ class FusedAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, prepared=False):
+        if closure is not None:
+            raise BtsAmdError("FusedAdamW.step() does not support a closure (bts_main.py never passes one)")
         if not prepared:
             self.prepare_step()
         rows = self._rows()

@@ -1,0 +1,394 @@
+// Probe (gfx950): does a DEEPER staging pipeline lift the conv_wgrad_tr structure off its ~0.31-of-peak plateau?
+//
+// tools/probes/wgrad_tile_probe.hip (round 3, gpurun r03a) showed that larger tiles alone do not: 128x128 / 128x256 / 256x256 all
+// land at 780-810 TF on the conv5 weight-gradient shape although the MAC per staged byte doubles.  What the variants share is the
+// two-stage ring with `s_waitcnt vmcnt(0)` in front of the per-chunk barrier: the LDS-DMA pieces of chunk c+1 are issued
+// between the MFMAs of chunk c and must ALL have landed when chunk c ends, i.e. the youngest piece gets a few dozen cycles
+// where an L2 hit needs 250-400 and an HBM miss ~900 (MI355X_MICROARCH.md latency table).  With two 4-wave workgroups per CU
+// the partner covers part of the stall; an 8-wave 256x256 workgroup has no partner and loses what its tile gained.
+//
+// This probe keeps everything else (pixel-major operands staged as they lie, ds_read_b64_tr_b16 fragments, 64-byte half swap,
+// reads and DMA issues between individual MFMAs) and templates the ring:
+//
+//      KC   K rows per chunk (64 or 32)            NST  ring stages (2 = the shipped form: vmcnt(0))
+//      PF   0: wait + barrier at the chunk start, first k-step's fragments read behind it (shipped form)
+//           1: wait + barrier in front of the chunk's LAST k-step; the first k-step of the next chunk is read across the
+//              boundary (no exposed LDS latency per chunk), all DMA issues of the chunk sit in front of that wait
+//      the wait is vmcnt((NST-2) * G): stage c+1 has landed, the NST-2 younger stages may still be in flight
+//      ABL  0 full | 1 no MFMA, no fragment reads (staging only) | 2 no DMA (MFMA + reads on whatever LDS holds): timing only
+//
+// Part 1 checks every variant against a host GEMM on ragged sizes; part 2 times them on the weight-gradient shapes.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/wgrad_pipe_probe.hip -o tools/probes/wgrad_pipe_probe
+#include "../../bts_amd/csrc/conv_common.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+#include <vector>
+
+using namespace bts_conv;
+
+#define HIPCHECK(x)                                                                             \
+    do {                                                                                        \
+        hipError_t e_ = (x);                                                                    \
+        if (e_ != hipSuccess) {                                                                 \
+            fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            exit(2);                                                                            \
+        }                                                                                       \
+    } while (0)
+
+struct GemmP {
+    const uint16_t* A; int lda;      // [K][lda] bf16, M valid columns
+    const uint16_t* B; int ldb;      // [K][ldb] bf16, N valid columns
+    float* C; int ldc;               // [M][ldc] f32, accumulated into
+    int M, N, K;                     // M % 8 == 0, N % 8 == 0
+    int n_m_tiles, n_n_tiles, nchunks, chunks_per_split;
+};
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int OFF>
+__device__ __forceinline__ void tr_issue(u32x2_t& d, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+struct Frag { u32x2_t lo, hi; };
+__device__ __forceinline__ u32x4_t frag_vec(const Frag& f) { return u32x4_t{f.lo.x, f.lo.y, f.hi.x, f.hi.y}; }
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+constexpr int KC_UNUSED = 0;
+
+template <int WR, int WC, int FA, int FB, int KC, int NST, int PF, int ABL>
+__global__ __launch_bounds__(WR* WC * 64) void gemm_tn_ring(const GemmP a) {
+    constexpr int NT = WR * WC * 64, TM = WR * FA * 32, TN = WC * FB * 32;
+    constexpr int NSA = TM / 64, NSB = TN / 64, NSUB = NSA + NSB;
+    constexpr int SUB = KC * 128;           // one sub-tile: KC rows x 64 columns (128 B)
+    constexpr int RPI = NT / 8;             // stage rows one DMA instruction of the whole workgroup covers (1 KiB per wave)
+    constexpr int ROWS = NSUB * KC;         // rows of a stage (sub-tiles stacked)
+    constexpr int G = ROWS / RPI;           // DMA instructions per thread per chunk
+    constexpr int STAGE = NSUB * SUB;
+    constexpr int KS = KC / 16;             // k-steps per chunk
+    constexpr int KSD = PF ? KS - 1 : KS;   // k-steps that carry DMA issues
+    constexpr int NM = FA * FB;             // MFMAs per k-step per wave
+    constexpr int R = 2 * (FA + FB);        // transposing reads per k-step per wave
+    static_assert(FA % 2 == 0 && FB % 2 == 0 && ROWS % RPI == 0 && (KC % RPI == 0 || RPI % KC == 0) && G <= 32 && KS % 2 == 0, "shape");
+    static_assert(NST >= 2 && (!PF || KS >= 2), "ring");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NST stages
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.y;
+    const int L = remap_xcd(blockIdx.x, a.n_m_tiles * a.n_n_tiles);
+    const int mt = L % a.n_m_tiles, nt = L / a.n_m_tiles;
+    const char* zero = (const char*)kZeroPage;
+
+    // ---- DMA roles: instruction d of a chunk covers stage rows d*RPI .. d*RPI+RPI-1 (sub-tiles stacked, KC rows each); this
+    // thread fetches physical 16-byte piece pc of row d*RPI + g ------------------------------------------------------------------
+    const int pc = tid & 7, g8 = tid >> 3;
+    const int lp = pc ^ (((g8 >> 1) & 1) << 2);      // logical piece (rows 2,3 mod 4 keep their 64-byte halves swapped)
+    const char* cbase[G];                            // column base of the sub-tile the row belongs to (nullptr: outside M / N)
+    int krow[G], ldk[G];                             // K row inside the chunk, leading dimension (elements)
+#pragma unroll
+    for (int d = 0; d < G; ++d) {
+        const int Lr = d * RPI + g8, q = Lr / KC;
+        krow[d] = Lr % KC;
+        if (q < NSA) {
+            const int c = mt * TM + q * 64 + lp * 8;
+            cbase[d] = c < a.M ? (const char*)(a.A + c) : nullptr;
+            ldk[d] = a.lda;
+        } else {
+            const int c = nt * TN + (q - NSA) * 64 + lp * 8;
+            cbase[d] = c < a.N ? (const char*)(a.B + c) : nullptr;
+            ldk[d] = a.ldb;
+        }
+    }
+    const int c_begin = split * a.chunks_per_split;
+    const int c_end = min(a.nchunks, c_begin + a.chunks_per_split);
+    auto dma = [&](int chunk, char* stage, auto dc) {
+        constexpr int d = decltype(dc)::value;
+        if constexpr (ABL != 2) {
+            const int m = chunk * KC + krow[d];
+            const bool on = chunk < c_end && m < a.K && cbase[d];
+            const char* src = on ? cbase[d] + (size_t)m * ldk[d] * 2 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(stage + (d * RPI + wave * 8) * 128), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment roles (lane -> row / 8-byte column group of the [4][16] block a 16-lane group reads) ------------------------
+    const int wr = wave / WC, wc = wave % WC;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int key = i16 >> 2, cg = i16 & 3, kb = g >> 1, chh = g & 1;
+    const int sw = (key >> 1) & 1;
+    uint32_t fo[FA + FB];                    // byte offset of every fragment's first read inside a stage
+#pragma unroll
+    for (int f = 0; f < FA + FB; ++f) {
+        const int c32 = f < FA ? wr * FA + f : wc * FB + (f - FA);         // 32-column block of the tile's A (B) side
+        const int sub = (f < FA ? 0 : NSA) + (c32 >> 1), half = c32 & 1;
+        fo[f] = sub * SUB + (kb * 8 + key) * 128 + ((half ^ sw) << 6) + chh * 32 + cg * 8;
+    }
+
+    f32x16_t acc[FA][FB];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < FB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const uint32_t s0 = lds_addr(smem);
+    Frag fr[2][FA + FB];
+    auto rd = [&](auto setc, auto sc, auto rc, uint32_t sT) {     // read rc of k-step sc of the stage at sT into fragment set setc
+        constexpr int set = decltype(setc)::value, S = decltype(sc)::value, r = decltype(rc)::value, f = r >> 1;
+        if constexpr (ABL != 1) {
+            if constexpr (r & 1) tr_issue<S * 16 * 128 + 512>(fr[set][f].hi, sT + fo[f]);
+            else tr_issue<S * 16 * 128>(fr[set][f].lo, sT + fo[f]);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+
+    // prologue: NST-1 stages in flight
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) static_for<G>([&](auto dc) { dma(c_begin + s, smem + s * STAGE, dc); });
+    int rb = 0;                                                    // ring index of the chunk being multiplied
+    if constexpr (PF) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * G) : "memory");
+        __builtin_amdgcn_s_barrier();
+        static_for<R>([&](auto rc) { rd(I0{}, I0{}, rc, s0); });
+    }
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const int wbuf = rb == 0 ? NST - 1 : rb - 1;               // stage of chunk-1 == stage of chunk+NST-1: refilled during this chunk
+        const int nbuf = rb + 1 == NST ? 0 : rb + 1;
+        const uint32_t sT = s0 + rb * STAGE, sN = s0 + nbuf * STAGE;
+        char* stw = smem + wbuf * STAGE;
+        if constexpr (!PF) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * G) : "memory");   // this chunk's stage has landed (own pieces)
+            __builtin_amdgcn_s_barrier();                          // ... everyone's, and everyone is done reading stage wbuf
+            static_for<R>([&](auto rc) { rd(I0{}, I0{}, rc, sT); });
+        }
+        static_for<KS>([&](auto sc) {
+            constexpr int S = decltype(sc)::value, CUR = S & 1, NXT = CUR ^ 1;
+            if constexpr (PF && S == KS - 1) {
+                // every DMA of this chunk has been issued: stage chunk+1 landed = at most the NST-2 younger stages outstanding;
+                // own fragment reads returned (WAR for the refill of this stage next chunk), then publish
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * G) : "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the R reads of k-step S have returned
+            }
+            static_for<NM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value, i = m / FB, j = m % FB;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ABL != 1) Mma<BF16>::run(frag_vec(fr[CUR][i]), frag_vec(fr[CUR][FA + j]), acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int r_lo = m * R / NM, r_hi = (m + 1) * R / NM;
+                if constexpr (S + 1 < KS) {
+                    static_for<r_hi - r_lo>([&](auto k) {
+                        rd(std::integral_constant<int, NXT>{}, std::integral_constant<int, S + 1>{},
+                           std::integral_constant<int, r_lo + decltype(k)::value>{}, sT);
+                    });
+                } else if constexpr (PF) {
+                    static_for<r_hi - r_lo>([&](auto k) {
+                        rd(std::integral_constant<int, NXT>{}, I0{}, std::integral_constant<int, r_lo + decltype(k)::value>{}, sN);
+                    });
+                }
+                if constexpr (S < KSD) {
+                    constexpr int d_lo = (S * NM + m) * G / (KSD * NM), d_hi = (S * NM + m + 1) * G / (KSD * NM);
+                    static_for<d_hi - d_lo>([&](auto k) { dma(chunk + NST - 1, stw, std::integral_constant<int, d_lo + decltype(k)::value>{}); });
+                }
+            });
+        });
+        rb = nbuf;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tail DMAs (zero page) / the last unused prefetch
+
+    // ---- epilogue (as the product kernel after tools/r3_prep/0001: batched read-modify-write of full 32-row blocks) ----------
+    const int frow = lane & 31, fk = lane >> 5;
+    const bool single = gridDim.y == 1;
+#pragma unroll
+    for (int j = 0; j < FB; ++j) {
+        const int col = nt * TN + (wc * FB + j) * 32 + frow;
+        const bool col_ok = col < a.N;
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+            const int rbk = mt * TM + (wr * FA + i) * 32;
+            const int row0 = rbk + 4 * fk;
+            float* p0 = a.C + (size_t)row0 * a.ldc + (col_ok ? col : 0);
+            if (single && rbk + 32 <= a.M) {
+                if (col_ok) {
+                    float old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) old[r] = p0[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldc];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p0[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldc] = old[r] + acc[i][j][r];
+                }
+            } else if (col_ok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (row0 + dr >= a.M) continue;
+                    if (single) p0[(size_t)dr * a.ldc] += acc[i][j][r];
+                    else atomicAdd(p0 + (size_t)dr * a.ldc, acc[i][j][r]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+static float h_bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint16_t h_f2bf(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static uint32_t rng_state = 99u;
+static float frand() { rng_state = rng_state * 1664525u + 1013904223u; return (float)((rng_state >> 8) & 0xffff) / 32768.f - 1.f; }
+
+__global__ void fill_bf16(uint32_t* p, size_t n, uint32_t seed) {
+    for (size_t i = blockIdx.x * 256ul + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint32_t h = (uint32_t)i * 2654435761u + seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = ((h & 0x807fu) | 0x3f00u) | ((((h >> 16) & 0x807fu) | 0x3e80u) << 16);     // two bf16 in +-[0.25, 1)
+    }
+}
+
+template <int WR, int WC, int FA, int FB, int KC, int NST, int PF, int ABL>
+static void launch(GemmP p, int splits, hipStream_t st) {
+    constexpr int TM = WR * FA * 32, TN = WC * FB * 32, LDS = NST * (TM + TN) / 64 * KC * 128;
+    static_assert(LDS <= 160 * 1024, "LDS");
+    static bool attr = false;
+    if (!attr) {
+        HIPCHECK(hipFuncSetAttribute((const void*)gemm_tn_ring<WR, WC, FA, FB, KC, NST, PF, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    p.n_m_tiles = (p.M + TM - 1) / TM;
+    p.n_n_tiles = (p.N + TN - 1) / TN;
+    p.nchunks = (p.K + KC - 1) / KC;
+    if (splits > p.nchunks) splits = p.nchunks;
+    p.chunks_per_split = (p.nchunks + splits - 1) / splits;
+    splits = (p.nchunks + p.chunks_per_split - 1) / p.chunks_per_split;
+    hipLaunchKernelGGL((gemm_tn_ring<WR, WC, FA, FB, KC, NST, PF, ABL>), dim3(p.n_m_tiles * p.n_n_tiles, splits), dim3(WR * WC * 64), LDS, st, p);
+}
+
+struct Variant { const char* name; void (*fn)(GemmP, int, hipStream_t); int tm, tn, lds_kib; bool checked; };
+#define V_(WR, WC, FA, FB, KC, NST, PF, ABL) \
+    {#WR "x" #WC " f" #FA "x" #FB " KC" #KC " NST" #NST " PF" #PF " ABL" #ABL, launch<WR, WC, FA, FB, KC, NST, PF, ABL>, WR * FA * 32, WC * FB * 32, \
+     NST * (WR * FA * 32 + WC * FB * 32) / 64 * KC * 128 / 1024, ABL == 0}
+static const Variant variants[] = {
+    V_(2, 2, 2, 2, 64, 2, 0, 0),      // 128x128: the shipped structure
+    V_(2, 2, 2, 2, 64, 3, 0, 0),      // 96 KiB: one workgroup per CU, one more chunk in flight
+    V_(2, 2, 2, 2, 64, 3, 1, 0),
+    V_(2, 2, 2, 2, 32, 4, 0, 0),      // 64 KiB: two workgroups per CU, half-chunk ring
+    V_(2, 2, 2, 2, 32, 4, 1, 0),
+    V_(2, 4, 2, 2, 64, 2, 0, 0),      // 128x256
+    V_(2, 4, 2, 2, 64, 3, 0, 0),
+    V_(2, 4, 2, 2, 64, 3, 1, 0),
+    V_(2, 4, 2, 2, 32, 4, 1, 0),
+    V_(4, 2, 2, 2, 64, 3, 1, 0),      // 256x128
+    V_(2, 4, 4, 2, 64, 2, 0, 0),      // 256x256, wave = 128 x 64
+    V_(2, 4, 4, 2, 32, 4, 0, 0),
+    V_(2, 4, 4, 2, 32, 4, 1, 0),
+    V_(2, 4, 4, 2, 32, 5, 1, 0),      // all 160 KiB
+    V_(4, 2, 2, 4, 32, 4, 1, 0),      // 256x256, wave = 64 x 128
+    V_(2, 4, 4, 2, 32, 4, 1, 1),      // ablations of the 256x256 ring: staging only / MFMA + reads only
+    V_(2, 4, 4, 2, 32, 4, 1, 2),
+    V_(2, 2, 2, 2, 64, 2, 0, 1),      // ... and of the shipped structure
+    V_(2, 2, 2, 2, 64, 2, 0, 2),
+};
+
+static int n_fail = 0;
+static void check(const Variant& v, int M, int N, int K, int splits) {
+    const int lda = M + 8, ldb = N + 16, ldc = N + 3;
+    std::vector<uint16_t> hA((size_t)K * lda), hB((size_t)K * ldb);
+    for (auto& x : hA) x = h_f2bf(frand());
+    for (auto& x : hB) x = h_f2bf(frand());
+    std::vector<float> hC((size_t)M * ldc, 0.f), ref((size_t)M * ldc, 0.f);
+    for (auto& x : hC) x = frand();                       // the kernel accumulates into C
+    ref = hC;
+    for (int k = 0; k < K; ++k)
+        for (int m = 0; m < M; ++m) {
+            const float av = h_bf2f(hA[(size_t)k * lda + m]);
+            for (int n = 0; n < N; ++n) ref[(size_t)m * ldc + n] += av * h_bf2f(hB[(size_t)k * ldb + n]);
+        }
+    uint16_t *dA, *dB; float* dC;
+    HIPCHECK(hipMalloc(&dA, hA.size() * 2)); HIPCHECK(hipMalloc(&dB, hB.size() * 2)); HIPCHECK(hipMalloc(&dC, hC.size() * 4));
+    HIPCHECK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dC, hC.data(), hC.size() * 4, hipMemcpyHostToDevice));
+    GemmP p{dA, lda, dB, ldb, dC, ldc, M, N, K, 0, 0, 0, 0};
+    v.fn(p, splits, nullptr);
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+    double err = 0, mag = 0;
+    for (size_t i = 0; i < hC.size(); ++i) { err = fmax(err, fabs((double)hC[i] - ref[i])); mag = fmax(mag, fabs((double)ref[i])); }
+    const bool ok = err <= 2e-4 * mag;     // f32 accumulation in a different order; padding columns of C must be untouched (err 0 there)
+    if (!ok) ++n_fail;
+    printf("{\"check\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"splits\": %d, \"max_err\": %.3g, \"max_ref\": %.3g, \"ok\": %s}\n", v.name, M, N, K,
+           splits, err, mag, ok ? "true" : "false");
+    HIPCHECK(hipFree(dA)); HIPCHECK(hipFree(dB)); HIPCHECK(hipFree(dC));
+}
+
+int main(int argc, char** argv) {
+    const bool check_only = argc > 1 && !strcmp(argv[1], "--check-only");
+    HIPCHECK(hipSetDevice(0));
+    for (const Variant& v : variants) {
+        if (!v.checked) continue;
+        check(v, 320, 200, 200, 1);        // partial second tile on both sides, ragged last chunk
+        check(v, 256, 512, 448, 3);        // several chunks per split, 3-way split with atomics
+        check(v, 72, 40, 64, 1);           // smaller than one tile
+    }
+    printf("{\"failed\": %d}\n", n_fail);
+    fflush(stdout);
+    if (check_only) return n_fail ? 1 : 0;
+
+    // weight-gradient shapes of the train step (8 x 352 x 1216 input): M = Cout, N = taps x Cin, K = output pixels
+    struct Shape { const char* name; int M, N, K; };
+    const Shape shapes[] = {{"conv5", 512, 9 * 896, 13376},     {"conv4", 256, 9 * 448, 53504},    {"daspp_conv", 128, 9 * 448, 53504},
+                            {"conv3", 128, 9 * 232, 214016},    {"daspp1x1_24", 128, 704, 53504},  {"upconv5/phase", 512, 4 * 2208, 3344}};
+    size_t maxA = 0, maxB = 0, maxC = 0;
+    for (const Shape& s : shapes) {
+        maxA = std::max(maxA, (size_t)s.K * s.M); maxB = std::max(maxB, (size_t)s.K * s.N); maxC = std::max(maxC, (size_t)s.M * s.N);
+    }
+    uint16_t *dA, *dB; float* dC;
+    HIPCHECK(hipMalloc(&dA, maxA * 2)); HIPCHECK(hipMalloc(&dB, maxB * 2)); HIPCHECK(hipMalloc(&dC, maxC * 4));
+    hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, (uint32_t*)dA, maxA / 2, 1u);
+    hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, (uint32_t*)dB, maxB / 2, 2u);
+    HIPCHECK(hipMemset(dC, 0, maxC * 4));
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+    for (const Shape& s : shapes)
+        for (const Variant& v : variants) {
+            const int tiles = ((s.M + v.tm - 1) / v.tm) * ((s.N + v.tn - 1) / v.tn);
+            const int per_cu = v.lds_kib <= 80 ? 2 : 1;
+            // candidate pixel splits: fill one round of the chip, and twice that
+            for (int mult = 1; mult <= 2; ++mult) {
+                int splits = std::max(1, 256 * per_cu * mult / tiles);
+                GemmP p{dA, s.M, dB, s.N, dC, s.N, s.M, s.N, s.K, 0, 0, 0, 0};
+                for (int i = 0; i < 2; ++i) v.fn(p, splits, nullptr);
+                HIPCHECK(hipEventRecord(e0, 0));
+                const int iters = 10;
+                for (int i = 0; i < iters; ++i) v.fn(p, splits, nullptr);
+                HIPCHECK(hipEventRecord(e1, 0));
+                HIPCHECK(hipEventSynchronize(e1));
+                float ms; HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+                const double us = ms * 1000.0 / iters, tf = 2.0 * s.M * s.N * (double)s.K / us * 1e-6;
+                printf("{\"shape\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"variant\": \"%s\", \"tiles\": %d, \"splits\": %d, \"us\": %.1f, \"TF\": %.0f}\n",
+                       s.name, s.M, s.N, s.K, v.name, tiles, splits, us, tf);
+                if (tiles >= 256 * per_cu) break;      // no split to vary
+            }
+            fflush(stdout);
+        }
+    HIPCHECK(hipDeviceSynchronize());
+    printf("{\"done\": true, \"last_error\": \"%s\"}\n", hipGetErrorString(hipGetLastError()));
+    return n_fail ? 1 : 0;
+}
