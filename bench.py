@@ -59,6 +59,9 @@ def parse():
                          "bts_amd.parallel.GradAllReducer from hooks (eager, overlapped); bts-graph = hipGraph(fwd+bwd) -> "
                          "GradAllReducer.reduce_all() -> hipGraph(AdamW); auto = bts (the eager step is GPU-bound: 61.1 ms eager vs 60.9 ms "
                          "replayed at N=1, and bts costs +1.2 ms at world 1 against +3.1 ms for ddp and +3.2 ms for bts-graph)")
+    ap.add_argument("--parity", type=int, default=1, help="one-batch parity figures (decoder vs the device-side checker) in the JSON line; N=1 only")
+    ap.add_argument("--lpg-op", type=int, default=1, help="time the bare LPG operator at the bench shape (BASELINE metric ii); N=1 only")
+    ap.add_argument("--dump-launches", default="", help="write the per-launch table of the event-timed steps (family, layer tag, us, work) to this JSON file")
     ap.add_argument("--force-dist", type=int, default=0, help=argparse.SUPPRESS)   # world-1 process group: exercises the N>1 path on one GPU
     return ap.parse_args()
 
@@ -72,12 +75,12 @@ def set_misc(model):
 
 
 def make_batch(args, dev, seed):
-    from oracle import bts_oracle as O     # synthetic-input recipe shared with the tests
+    from bts_amd import synth              # synthetic-input recipe; the tests hold it equal to the oracle's
     gen = torch.Generator().manual_seed(seed)
     B, H, W = args.batch, args.height, args.width
     image = torch.randn(B, 3, H, W, generator=gen)
-    focal = O.synth_focal(B, args.dataset)
-    gt = O.synth_depth_gt(B, H, W, args.dataset, gen)
+    focal = synth.synth_focal(B, args.dataset)
+    gt = synth.synth_depth_gt(B, H, W, args.dataset, gen)
     return image.to(dev), focal.to(dev), gt.to(dev)
 
 
@@ -154,11 +157,19 @@ def cpu_baseline_subprocess(args, timeout_s=240):
                 "sample": "cpu baseline exceeded %d s on this host and was cut" % timeout_s}
 
 
+def library_md5():
+    import hashlib
+    from bts_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        return hashlib.md5(f.read()).hexdigest()
+
+
 def attach_traffic(roof):
-    """roofline.traffic = measured HBM bytes per launch of the kernel family (FETCH_SIZE / WRITE_SIZE PMC passes of THIS
-    bench command, collected and corrected as MI355X_MICROARCH.md prescribes and summarised by tools/pmc_table.py into
-    profiles/pmc_traffic.json).  PMC counters cannot be read inside the process, so the committed summary is looked up by
-    kernel family; null when the family (or the file) is absent."""
+    """roofline.traffic = measured fabric-side bytes per launch of the kernel family (FETCH_SIZE / WRITE_SIZE PMC passes of THIS
+    bench command, collected and corrected as MI355X_MICROARCH.md prescribes and summarised by tools/pmc_traffic.py into
+    profiles/pmc_traffic.json).  PMC counters cannot be read inside the process, so the committed summary is looked up by kernel
+    family -- and only counts as a measurement of THIS run when it was taken on the same binary: the file records the md5 of the
+    libbts_amd.so it profiled; on a mismatch the figures go under `traffic_archived` (with that md5) and `traffic` stays null."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not roof or not os.path.exists(path):
         return
@@ -167,14 +178,105 @@ def attach_traffic(roof):
             table = json.load(f)
     except (OSError, ValueError):
         return
-    for key in ("roofline", "roofline_lpg"):
+    meta = table.get("_meta", {})
+    same = bool(meta.get("library_md5")) and meta.get("library_md5") == library_md5()
+    for key in ("roofline", "roofline_lpg", "roofline_elementwise"):
         r = roof.get(key)
         if not r:
             continue
         ent = table.get(r["kernel"]) or table.get(r["kernel"].split(" ")[0])
-        if ent:
+        if not ent:
+            continue
+        if same:
             r["traffic"] = ent.get("bytes_per_launch")
-            r["traffic_source"] = ent.get("source")
+            r["traffic_source"] = "%s; library md5 %s = the binary timed here" % (ent.get("source"), meta.get("library_md5"))
+        else:
+            r["traffic_archived"] = {"bytes_per_launch": ent.get("bytes_per_launch"), "library_md5": meta.get("library_md5"),
+                                     "note": "PMC passes of an EARLIER build of libbts_amd.so: not a measurement of this run"}
+
+
+def parity_check(args, model, image, focal, dev):
+    """One-batch parity figures for the JSON line, taken before the timed region: the decoder as it is about to be timed (bench
+    dtype, fused LPG chains) and in f32, both against the checker -- the oracle's formulas (oracle/bts_oracle.py, restating
+    bts.py:196-266) evaluated in f32 with torch ops on the device, on the SAME encoder features.  The oracle is used here only as
+    the checker, outside the timed region; nothing of the timed step routes through it."""
+    from bts_amd.model import bts
+    from oracle import bts_oracle as O
+
+    def l2(a, b):
+        a, b = a.double(), b.double()
+        return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+    def mx(a, b):
+        a, b = a.double(), b.double()
+        return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+    nb = min(2, image.shape[0])
+    md = 80.0 if args.dataset == "kitti" else 10.0
+    was_training = model.training
+    try:
+        with torch.no_grad():
+            model.eval()                                    # encoder BN in eval mode: features only need to be realistic
+            feats = [f.float() for f in model.encoder(image[:nb])]
+            P = {k: v.detach().clone() for k, v in model.decoder.state_dict().items()}
+            with torch.backends.cudnn.flags(enabled=False):
+                ref, _ = O.decoder_forward(P, feats, focal[:nb], md, args.dataset, True)
+            out = {"checker": "oracle formulas (bts.py:196-266), f32 torch ops on the device, same encoder features; train-mode "
+                              "BatchNorm; %d images" % nb}
+            for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+                dec = bts(NS(max_depth=md, dataset=args.dataset, encoder=args.encoder, bts_size=512, decoder_dtype=dt),
+                          model.encoder.feat_out_channels, 512).to(dev)
+                dec.load_state_dict(P)
+                dec.train()
+                got = dec([f.clone() for f in feats], focal[:nb])
+                out["%s_outputs_max" % tag] = float("%.3g" % max(mx(g, r) for g, r in zip(got, ref)))
+                out["%s_outputs_l2" % tag] = float("%.3g" % max(l2(g, r) for g, r in zip(got, ref)))
+                del dec
+        out["timed_dtype"] = args.dtype
+        return out
+    except Exception as e:   # noqa: BLE001  (reported, never fatal for the measurement)
+        return {"error": str(e)[:200]}
+    finally:
+        model.train(was_training)
+        torch.cuda.empty_cache()
+
+
+def lpg_op_roofline(B, H, W, iters=20):
+    """BASELINE metric (ii), "LPG HBM GB/s": the bare LPG operator (the reference's native op boundary, bts_lpg_fwd / bts_lpg_bwd =
+    local_planar_guidance.h:22-49) at the bench shape, k = 8, 4, 2, forward and backward, HIP events on the launching stream,
+    every launch on different buffers of a rotation larger than the 256 MiB Infinity Cache (so the rate is an HBM rate).
+    Algorithmic bytes: forward P*4*(1 + 4/k^2), backward P*4*(1 + 8/k^2) per image."""
+    from bts_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    res, tot_b, tot_s = {}, 0.0, 0.0
+    for k in (8, 4, 2):
+        h, w = H // k, W // k
+        per = B * H * W * 4 * 2 + B * h * w * 16 * 2
+        nrot = max(2, ((768 << 20) + per - 1) // per)
+        eqs = [torch.randn(B, h, w, 4, device=dev) for _ in range(nrot)]
+        gs = [torch.randn(B, H, W, device=dev) for _ in range(nrot)]
+        for name, fn, byts in (("fwd", lambda i: ops.lpg_fwd(eqs[i], k), B * H * W * 4 * (1 + 4.0 / (k * k))),
+                               ("bwd", lambda i: ops.lpg_bwd(gs[i], eqs[i], k), B * H * W * 4 * (1 + 8.0 / (k * k)))):
+            keep = [fn(i) for i in range(nrot)]
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            n = 0
+            while n < iters:
+                for i in range(nrot):
+                    keep[i] = fn(i)
+                    n += 1
+            e.record()
+            torch.cuda.synchronize()
+            sec = s.elapsed_time(e) * 1e-3 / n
+            res["k%d_%s_GBps" % (k, name)] = round(byts / sec / 1e9, 1)
+            tot_b += byts
+            tot_s += sec
+        del eqs, gs, keep
+    torch.cuda.empty_cache()
+    ach = tot_b / tot_s / 1e9
+    return {"kernel": "lpg_fwd/bwd_kernel<k=8,4,2> (bare LPG operator, TF-op boundary)", "bound": "hbm", "achieved": round(ach, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "alg_bytes_per_launch": round(tot_b / 6), "shape": "%dx%dx%d" % (B, H, W), "hbm_resident": True, "per_kernel": res}
 
 
 def infer_main(args):
@@ -195,7 +297,8 @@ def infer_main(args):
     model.eval()
     gen = torch.Generator().manual_seed(99)
     image = torch.randn(B, 3, H, W, generator=gen)
-    focal = O.synth_focal(B, "kitti")
+    from bts_amd import synth
+    focal = synth.synth_focal(B, "kitti")
     ref_depth = None
     if not args.no_cpu_baseline:
         torch.set_num_threads(min(os.cpu_count() or 1, 64))
@@ -307,6 +410,7 @@ def main():
     if args.channels_last:
         image = image.contiguous(memory_format=torch.channels_last)
     mask = gt > (1.0 if args.dataset == "kitti" else 0.1)
+    parity = parity_check(args, model, image, focal, dev) if (args.parity and world == 1 and rank == 0) else None
     total_steps = 50 * 1000
     gstep = [0]
 
@@ -451,6 +555,19 @@ def main():
         roof = prof.summary(PEAK[args.dtype], HBM_PEAK_GBS, args.steps)
         if (args.encoder, args.height, args.width, args.batch, args.dtype) == ("densenet161_bts", 352, 1216, 8, "bf16"):
             attach_traffic(roof)        # the PMC passes were taken on this configuration only
+        roof["library_md5"] = library_md5()
+        if args.dump_launches:
+            agg = {}
+            for family, tag, us, work in prof.launches():
+                a = agg.setdefault((family, tag or ""), [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += us
+                a[2] += work
+            rows = [{"family": k[0], "tag": k[1], "launches_per_step": round(v[0] / args.steps, 2), "us_per_launch": round(v[1] / v[0], 2),
+                     "us_per_step": round(v[1] / args.steps, 2), "work_per_launch": v[2] / v[0]} for k, v in agg.items()]
+            rows.sort(key=lambda r: -r["us_per_step"])
+            with open(args.dump_launches, "w") as f:
+                json.dump({"library_md5": roof["library_md5"], "steps": args.steps, "rows": rows}, f, indent=0)
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         out = {
@@ -468,6 +585,13 @@ def main():
         }
         if roof is not None:
             out.update(roof)
+        if parity is not None:
+            out["parity"] = parity
+        if args.lpg_op and world == 1:
+            try:
+                out["roofline_lpg_op"] = lpg_op_roofline(args.batch, args.height, args.width)
+            except Exception as e:   # noqa: BLE001
+                out["roofline_lpg_op"] = {"error": str(e)[:160]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(out), flush=True)

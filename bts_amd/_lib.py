@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libbts_amd.so")
 
 BTS_F32, BTS_BF16 = 0, 1
 ACT_NONE, ACT_ELU, ACT_SIGMOID, ACT_RELU = 0, 1, 2, 3
-MAX_SEG, MAX_TAP = 6, 16
+MAX_SEG, MAX_TAP, BN_MAX_SEG = 6, 16, 6
 ERRORS = {-1: "BTS_ERR_ARG", -2: "BTS_ERR_LAUNCH", -3: "BTS_ERR_UNSUPPORTED"}
 
 
@@ -60,6 +60,18 @@ class UnpackJob(C.Structure):
                 ("tapmask", C.c_uint16 * MAX_TAP), ("first_block", C.c_int32)]
 
 
+class BnSeg(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dx", C.c_void_p), ("mean", C.c_void_p), ("var", C.c_void_p),
+                ("C", C.c_int32), ("x_stride", C.c_int32), ("dx_stride", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class BnDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("nseg", C.c_int32), ("M", C.c_int64), ("seg", BnSeg * BN_MAX_SEG),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("eps", C.c_float), ("momentum", C.c_float), ("relu", C.c_int32), ("use_batch_stats", C.c_int32),
+                ("y", C.c_void_p), ("y_stride", C.c_int32), ("elu_x", C.c_int32), ("y2", C.c_void_p), ("y2_stride", C.c_int32)]
+
+
 _i, _l, _f, _p = C.c_int, C.c_long, C.c_float, C.c_void_p
 
 # name -> argtypes (restype is int unless listed in _LONG_RET); mirrors include/bts_amd.h exactly
@@ -95,12 +107,15 @@ SIGNATURES = {
     "bts_affine_act": [_p, _i, _i, _p, _i, _i, _l, _i, _p, _p, _i, _p],
     "bts_bn_bwd_reduce": [_p, _i, _p, _i, _i, _l, _i, _p, _p, _p, _p, _i, _p, _p, _p],
     "bts_bn_bwd_apply": [_p, _i, _p, _i, _p, _i, _i, _l, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p],
-    "bts_act_bwd": [_p, _i, _i, _p, _i, _i, _p, _i, _i, _l, _i, _i, _f, _p, _l, _p],
+    "bts_bn_apply": [C.POINTER(BnDesc), _p],
+    "bts_bn_bwd_workspace_bytes": [C.POINTER(BnDesc)],
+    "bts_bn_bwd": [C.POINTER(BnDesc), _p, _p, _p],
+    "bts_act_bwd": [_p, _i, _i, _p, _i, _i, _p, _i, _i, _l, _i, _i, _f, _p, _l, _i, _p],
     "bts_add_to": [_p, _i, _i, _p, _i, _i, _l, _i, _i, _p],
     "bts_adamw_step": [_p, _p, _p, _p, _p, _i, _l, _f, _f, _f, _f, _f, _f, _f, _p, _p],
     "bts_adamw_advance": [_p, _i, _p],
 }
-_LONG_RET = {"bts_silog_workspace_bytes", "bts_bn_stats_workspace_bytes", "bts_eval_workspace_bytes"}
+_LONG_RET = {"bts_silog_workspace_bytes", "bts_bn_stats_workspace_bytes", "bts_eval_workspace_bytes", "bts_bn_bwd_workspace_bytes"}
 _NO_CHECK = _LONG_RET | {"bts_abi_version", "bts_current_device"}
 
 _lib = None
@@ -120,7 +135,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.argtypes = args
         fn.restype = C.c_long if name in _LONG_RET else C.c_int
-    if lib.bts_abi_version() != 1:
+    if lib.bts_abi_version() != 2:
         raise BtsAmdError("libbts_amd.so ABI version mismatch")
     _lib = lib
     return lib
@@ -129,17 +144,16 @@ def load():
 def call(name, *args):
     """Invoke an entry point and raise on a non-zero status."""
     from . import profiler
-    if profiler.ACTIVE is not None:
-        note = profiler.take()
-        if note is not None:
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            rc = getattr(load(), name)(*args)
-            e.record()
-            profiler.ACTIVE.add(note[0], note[1], note[2], s, e)
-            if rc != 0:
-                raise BtsAmdError("%s failed: %s (%d)" % (name, ERRORS.get(rc, "?"), rc))
-            return rc
+    if profiler.ACTIVE is not None and name not in _NO_CHECK:
+        note = profiler.take() or (name[4:], "hbm", 0.0, None)      # undescribed launches are still timed (zero work)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = getattr(load(), name)(*args)
+        e.record()
+        profiler.ACTIVE.add(note[0], note[1], note[2], s, e, note[3])
+        if rc != 0:
+            raise BtsAmdError("%s failed: %s (%d)" % (name, ERRORS.get(rc, "?"), rc))
+        return rc
     rc = getattr(load(), name)(*args)
     if name not in _NO_CHECK and rc != 0:
         raise BtsAmdError("%s failed: %s (%d)" % (name, ERRORS.get(rc, "?"), rc))

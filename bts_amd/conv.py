@@ -81,12 +81,20 @@ def _wide_pays(cout, n, hg, wg):
     return fill >= 0.70
 
 
+_CONV_BIG_DEFAULT = "t"      # launch_fwd()'s default schedule letter (csrc/conv_igemm.hip)
+
+
 def _fwd_kernel(dtype, cout, halo, geom=None, kv=8, up=False):
     """Name of the kernel launch_fwd() (csrc/conv_igemm.hip) picks: profiler label = rocprofv3 kernel family."""
     if halo and cout <= 64:
         return "conv_halo<%s>" % _dn(dtype)
     if halo and not up and dtype == torch.bfloat16 and kv >= 8 and geom is not None and _wide_pays(cout, *geom):
         return "conv_halo_wide<bf16,128x256>"
+    if cout > 64 and geom is not None:
+        big = os.environ.get("BTS_CONV_BIG", _CONV_BIG_DEFAULT)[:1]
+        wgs = _cdiv(cout, 128) * _cdiv(geom[0] * geom[1] * geom[2], 256) * (4 if up else 1)
+        if big == "u" or (big == "w" and wgs >= int(os.environ.get("BTS_RING_MIN_WGS", "160"))):
+            return "conv_igemm_dma<%s,128x256,ring3>" % _dn(dtype)
     return "conv_igemm_dma<%s,%s>" % (_dn(dtype), "128x128" if cout > 64 else ("64x128" if cout > 32 else "32x256"))
 
 
@@ -96,8 +104,8 @@ def _wgrad_kernel(dtype, cout, radius1, up, n, hg, wg):
         return "conv_wgrad_c1<%s>" % _dn(dtype)
     if radius1 and cout <= 64 and dtype == torch.bfloat16 and _cdiv(wg, 32) * _cdiv(hg, 8) * n >= 256:
         return "conv_wgrad_halo_up<bf16>" if up else "conv_wgrad_halo<bf16>"
-    if cout > 64 and dtype == torch.bfloat16 and os.environ.get("BTS_WGRAD_TR", "1")[:1] != "0":
-        return "conv_wgrad_tr<bf16,128x128>"
+    if cout > 64 and dtype == torch.bfloat16 and os.environ.get("BTS_WGRAD_TR", "2")[:1] != "0":
+        return "conv_wgrad_tr<bf16,128x128>" if os.environ.get("BTS_WGRAD_TR", "2")[:1] == "1" else "conv_wgrad_ring<bf16,128x256>"
     return "conv_wgrad<%s,%s>" % (_dn(dtype), "128x128" if cout > 64 else ("64x128k2" if cout > 32 else "32x128k4"))
 
 
@@ -209,7 +217,7 @@ class ConvLayer:
             M = N * Hx * Wx
             kv = sum(pad_to(c, vec_of(dtype)) for c in self.seg_channels) // vec_of(dtype)
             profiler.note(_fwd_kernel(dtype, self.cout, self.kk == 9 and self.dil == 1, (N, Hx, Wx), kv, self.up), "mfma",
-                          2.0 * M * self.nphase * self.T * self.cin * self.cout)
+                          2.0 * M * self.nphase * self.T * self.cin * self.cout, self.name + ".fwd")
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return out
 
@@ -248,7 +256,7 @@ class ConvLayer:
             cseg = self.seg_channels[seg_index]
             profiler.note(_fwd_kernel(dtype, gx.shape[3], self.kk == 9 and self.dil == 1 and not self.up, (N, Hg, Wg),
                                       pad_to(self.cout, vec_of(dtype)) // vec_of(dtype)), "mfma",
-                          2.0 * N * Hg * Wg * len(self.taps) * cseg * self.cout)
+                          2.0 * N * Hg * Wg * len(self.taps) * cseg * self.cout, "%s.dgrad%d" % (self.name, seg_index))
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return gx
 
@@ -266,7 +274,7 @@ class ConvLayer:
         d.osc = 2 if self.up else 1
         if profiler.ACTIVE is not None:
             profiler.note(_wgrad_kernel(dtype, self.cout, self.kk == 9 and self.dil == 1, self.up, N, Hx, Wx), "mfma",
-                          2.0 * N * Hx * Wx * self.nphase * self.T * self.cin * self.cout)
+                          2.0 * N * Hx * Wx * self.nphase * self.T * self.cin * self.cout, self.name + ".wgrad")
         call("bts_conv_wgrad", C.byref(d), C.c_void_p(dz.data_ptr()), pix_stride(dz), C.c_void_p(dwp.data_ptr()), stream_ptr())
         return dwp
 

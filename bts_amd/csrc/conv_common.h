@@ -3,7 +3,16 @@
 #pragma once
 #include "common.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace bts_conv {
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for_n(F&& f) { static_for_seq(std::make_integer_sequence<int, N>{}, f); }
 
 struct FastDiv {
     uint32_t m, s;

@@ -356,13 +356,86 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
 
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) { prep_chunk(s); fire_chunk(s); }
+    if constexpr (PF == 9) {
+        // Ring schedule (round 3; tools/probes/wgrad_pipe_probe.hip is the same pipeline as a plain GEMM, measured there first:
+        // conv5-shaped problem 758 -> 953 TF going from the 128x128 two-stage form to 128x256 with this ring).  What it changes
+        // against schedule t above:
+        //   * NS >= 3 stages and the per-chunk wait is vmcnt((NS-2)*G) in front of the chunk's LAST k-step: the DMA pieces of
+        //     chunk c+1 were issued a whole chunk earlier (during chunk c-1... c), not a few dozen cycles before the wait -- the
+        //     two-stage form drains vmcnt(0) at every chunk and its youngest piece has had no time to land;
+        //   * the barrier sits in front of the last k-step, so the first k-step of chunk c+1 is read ACROSS the chunk boundary
+        //     behind it (no exposed LDS round trip per chunk);
+        //   * all G DMA issues of a chunk sit between the MFMAs of its first three k-steps, the fragment reads of k-step s+1
+        //     between the MFMAs of k-step s -- any TM x TN, generated by compile-time loops instead of hand placement.
+        // RAW: a wave waits for its own pieces of chunk c+1 (everything but the NS-2 younger groups) before barrier(c); behind
+        // it every wave's pieces have landed.  WAR: the refill of chunk c-1's stage is issued during chunk c, behind
+        // barrier(c-1), which every wave reached with lgkmcnt(0), i.e. with its last reads of that stage returned.
+        static_assert(NS >= 3, "the ring needs a stage in flight beyond the one being published");
+        constexpr int R = TM + TN, NM = TM * TN;
+        const uint32_t s0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+        u32x4_t fa[2][TM], fb[2][TN];
+        auto rd = [&](u32x4_t& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); };
+        auto rdf = [&](auto setc, auto sc, auto rc, uint32_t sT) {      // fragment rc (A: 0..TM-1, B: TM..) of k-step sc
+            constexpr int set = decltype(setc)::value, ks = decltype(sc)::value, r = decltype(rc)::value;
+            const uint32_t kx = (uint32_t)(((2 * ks + fk) ^ swz) << 4);
+            if constexpr (r < TM) rd(fa[set][r], sT + offA[r] + kx);
+            else rd(fb[set][r - TM], sT + offB[r - TM] + kx);
+        };
+        auto dma = [&](char* stw, auto dc) {
+            constexpr int d = decltype(dc)::value;
+            if constexpr (d < RA) __builtin_amdgcn_global_load_lds((gptr_t)srcA[d], (lptr_t)(stw + (wave * 8 + RP * d) * 128), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((gptr_t)srcB[d - RA], (lptr_t)(stw + BM * 128 + (wave * 8 + RP * (d - RA)) * 128), 16, 0, 0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");
+        __builtin_amdgcn_s_barrier();
+        static_for_n<R>([&](auto rc) { rdf(I0{}, I0{}, rc, s0); });
+        int rb = 0;
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            prep_chunk(chunk + NS - 1);
+            const int wb = rb == 0 ? NS - 1 : rb - 1, nb = rb + 1 == NS ? 0 : rb + 1;
+            const uint32_t sT = s0 + rb * BUF, sN = s0 + nb * BUF;
+            char* stw = smem + wb * BUF;
+            static_for_n<4>([&](auto sc) {
+                constexpr int S = decltype(sc)::value, CUR = S & 1, NXT = CUR ^ 1;
+                if constexpr (S == 3) {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * G) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                if constexpr (S == 0) __builtin_amdgcn_s_setprio(1);
+                static_for_n<NM>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value, i = m / TN, j = m % TN;
+                    __builtin_amdgcn_sched_barrier(0);
+                    Mma<T>::run(fa[CUR][i], fb[CUR][j], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    constexpr int r_lo = m * R / NM, r_hi = (m + 1) * R / NM;
+                    static_for_n<r_hi - r_lo>([&](auto k) {
+                        using RC = std::integral_constant<int, r_lo + decltype(k)::value>;
+                        if constexpr (S < 3) rdf(std::integral_constant<int, NXT>{}, std::integral_constant<int, S + 1>{}, RC{}, sT);
+                        else rdf(std::integral_constant<int, NXT>{}, I0{}, RC{}, sN);
+                    });
+                    if constexpr (S < 3) {
+                        constexpr int d_lo = (S * NM + m) * G / (3 * NM), d_hi = (S * NM + m + 1) * G / (3 * NM);
+                        static_for_n<d_hi - d_lo>([&](auto k) { dma(stw, std::integral_constant<int, d_lo + decltype(k)::value>{}); });
+                    }
+                });
+                if constexpr (S == 3) __builtin_amdgcn_s_setprio(0);
+            });
+            rb = nb;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // zero-page tail groups, the last (unused) prefetch
+        conv_epilogue<T, WR, WC, TM, TN>(a, acc, co_tile, px_tile, phase, wr, wc, frow, fk);
+        return;
+    }
     int rbuf = 0, wbuf = NS - 1;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         prep_chunk(chunk + NS - 1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");   // this wave's part of `chunk` has landed
         __builtin_amdgcn_s_barrier();                                          // everyone's has; buffer wbuf is free
         const char* sT = smem + rbuf * BUF;
-        if constexpr (PF >= 8 && TM == 2 && TN == 2) {
+        if constexpr (PF == 8 && TM == 2 && TN == 2) {
             // Fine interleave (the lever on conv_halo_wide: +10 % there): the reads of k-step s+1 and the chunk's 8 DMA issues sit
             // between the individual MFMAs of k-step s, one or two per MFMA shadow, instead of in blocks in front of them.
             const uint32_t sTa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem + rbuf * BUF;
@@ -1750,6 +1823,12 @@ static bool use_lds_dma() {
     return v != 0;
 }
 
+// BTS_CONV_BIG=w: smallest grid (workgroups) the 128 x 256 ring kernel is given; below it the 128 x 128 form keeps more CUs busy
+static int ring_min_wgs() {
+    static const int v = [] { const char* e = getenv("BTS_RING_MIN_WGS"); return e ? atoi(e) : 160; }();
+    return v;
+}
+
 template <typename T>
 static int launch_fwd(const ConvK& k0, hipStream_t st) {
     ConvK k = k0;
@@ -1822,7 +1901,12 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
             if (rc != BTS_ERR_UNSUPPORTED) return rc;
         }
         if (k.Cout > 64) {
-            if (big == 'b') go2(conv_igemm_dma<T, 2, 2, 2, 2, 3>, 128, 128, 256);
+            // u: ring schedule (PF = 9, see the kernel), 128co x 256px, 8 waves, 3 stages (144 KiB); v: the same ring on the 128 x 128
+            // tile (96 KiB, one workgroup per CU) -- isolates the ring from the tile; w: u where it fills the chip, t elsewhere
+            const long ring_wgs = (long)ceil_div(k.Cout, 128) * ceil_div(k.M, 256) * k.nphase;
+            if (big == 'u' || (big == 'w' && ring_wgs >= ring_min_wgs())) go2(conv_igemm_dma<T, 2, 4, 2, 2, 3, 9>, 128, 256, 512);
+            else if (big == 'v') go2(conv_igemm_dma<T, 2, 2, 2, 2, 3, 9>, 128, 128, 256);
+            else if (big == 'b') go2(conv_igemm_dma<T, 2, 2, 2, 2, 3>, 128, 128, 256);
             else if (big == 'c') go2(conv_igemm_dma<T, 2, 4, 2, 2, 3>, 128, 256, 512);
             else if (big == 'd') go2(conv_igemm_dma<T, 2, 4, 2, 2, 2>, 128, 256, 512);
             else if (big == 'e' && k.Cout >= 256) go2(conv_igemm_dma<T, 2, 4, 4, 2, 2>, 256, 256, 512);   // experimental, see DESIGN §10

@@ -238,15 +238,240 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(const ConvK a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Ring form (round 3).  Same operands, same staging, same transposing reads; what changes is the pipeline around them:
+//
+//   * tile 128 co x 256 columns (WR x WC = 2 x 4 waves of 64 x 64), one 144 KiB workgroup per CU: the X rows a workgroup
+//     stages are shared by twice as many output channels' worth of dZ... and every dZ row by twice as many columns -- the
+//     fabric-side traffic of the 128 x 128 form was 5x the algorithmic bytes (profiles/pmc_traffic.json, round 2);
+//   * three stages and the per-chunk wait is vmcnt((NST-2)*G) in front of the chunk's LAST k-step: the pieces of chunk c+1
+//     were issued a whole chunk earlier.  The two-stage form waits vmcnt(0) at every chunk start, i.e. for pieces issued
+//     a few dozen cycles before (an L2 hit takes 250-400, MI355X_MICROARCH.md), and relies on the CU's second workgroup to
+//     cover the stall;
+//   * the barrier sits in front of the last k-step, so the first k-step of the next chunk is read across the chunk boundary.
+//
+// Measured first as a plain GEMM with the same pipeline (tools/probes/wgrad_pipe_probe.hip, gpurun r03b, conv5-shaped
+// problem): 128 x 128 two-stage 758 TF, 128 x 128 four half-stages 881, 128 x 256 two-stage 743, 128 x 256 three-stage ring
+// 953, 256 x 256 rings 814-827 (profiles/r03_wgrad_pipe_probe.jsonl).
+// RAW / WAR argument: see conv_igemm_dma's ring schedule (conv_igemm.hip), it is the same.
+template <int WR, int WC, int NST>
+__global__ __launch_bounds__(WR* WC * 64) void conv_wgrad_ring(const ConvK a) {
+    constexpr int NT = WR * WC * 64, TM = WR * 64, TN = WC * 64;
+    constexpr int NSA = TM / 64, NSB = TN / 64, NSUB = NSA + NSB;
+    constexpr int RPI = NT / 8;              // pixel rows one DMA instruction of the whole workgroup covers
+    constexpr int IPS = KC / RPI;            // instructions per sub-tile = pixel rows per thread
+    constexpr int GR = NSUB * IPS;           // DMA instructions per thread per chunk
+    constexpr int STG = NSUB * SUB;
+    constexpr int KS = KC / 16, NM = 4, R = 8;
+    static_assert(KC % RPI == 0 && (NST - 2) * GR <= 63 && NST >= 3, "shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int phase = blockIdx.z, split = blockIdx.y;
+    const int L = remap_xcd(blockIdx.x, a.n_co_tiles * a.n_col_tiles);
+    const int co_tile = L % a.n_co_tiles, col_tile = L / a.n_co_tiles;
+    const int pa = phase >> 1, pb = phase & 1;
+    const char* zero = (const char*)kZeroPage;
+
+    // ---- DMA roles: physical piece pc of pixel row r0 (+ RPI) of every sub-tile ---------------------------------------------
+    const int pc = tid & 7, r0 = tid >> 3;
+    const int lp = pc ^ (((r0 >> 1) & 1) << 2);                 // logical 16-byte piece this lane must fetch (half swap)
+    const char* abase[NSA];                                     // dZ + channel offset, or nullptr (beyond Cout)
+    const char* bbase[NSB];                                     // segment base + channel offset, or nullptr (beyond T*K)
+    uint32_t bsb[NSB];                                          // pixel stride of that segment, bytes
+    int bdy[NSB], bdx[NSB], btoff[NSB];
+#pragma unroll
+    for (int h = 0; h < NSA; ++h) {
+        const int co0 = co_tile * TM + h * 64 + lp * 8;
+        abase[h] = co0 < a.Cout ? a.dz + (size_t)co0 * 2 : nullptr;
+    }
+#pragma unroll
+    for (int h = 0; h < NSB; ++h) {
+        const int colv = col_tile * (TN / 8) + h * 8 + lp;
+        bbase[h] = nullptr; bsb[h] = 0; bdy[h] = bdx[h] = btoff[h] = 0;
+        if (colv < a.T * a.KV) {
+            const int t = colv / a.KV, cv = colv - t * a.KV;
+            const char* sp; int sst, coff;
+            pick_seg(a, cv, sp, sst, coff);
+            bbase[h] = sp + (size_t)coff * 16;
+            bsb[h] = (uint32_t)sst * 2u;
+            int ioy, iox;
+            decode_tap(a.taps[phase * a.T + t], bdy[h], bdx[h], ioy, iox);
+            btoff[h] = a.tapoff[phase * a.T + t];
+        }
+    }
+    const uint32_t asb = (uint32_t)a.dz_stride * 2u;
+    const int c_begin = split * a.chunks_per_split;
+    const int c_end = min(a.nchunks, c_begin + a.chunks_per_split);
+
+    const char* src[IPS][NSUB];   // [pixel row i][sub-tile]
+    auto prep = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < IPS; ++i) {
+            const int m = chunk * KC + r0 + RPI * i;
+            const bool on = chunk < c_end && m < a.M;
+            const uint32_t n = fdiv(on ? m : 0, a.fd_hw);
+            const uint32_t rem = (on ? m : 0) - n * (uint32_t)(a.Hg * a.Wg);
+            const uint32_t y = fdiv(rem, a.fd_w);
+            const uint32_t x = rem - y * a.Wg;
+            const uint32_t opix = (n * (uint32_t)a.Hy + y * a.osc + pa) * a.Wy + x * a.osc + pb;
+            const uint32_t ipix = n * (uint32_t)(a.Hx * a.Wx) + (uint32_t)a.isc * (y * a.Wx + x);
+            const uint32_t aoff = opix * asb;
+#pragma unroll
+            for (int h = 0; h < NSA; ++h) src[i][h] = (on && abase[h]) ? abase[h] + aoff : zero;
+#pragma unroll
+            for (int h = 0; h < NSB; ++h) {
+                const bool ok = on && bbase[h] && (unsigned)((int)y + bdy[h]) < (unsigned)a.Hg && (unsigned)((int)x + bdx[h]) < (unsigned)a.Wg;
+                src[i][NSA + h] = ok ? bbase[h] + (uint32_t)((int)ipix + btoff[h]) * bsb[h] : zero;
+            }
+        }
+    };
+    auto dma = [&](char* stage, auto dc) {                       // instruction d: sub-tile d / IPS, pixel row r0 + RPI * (d % IPS)
+        constexpr int d = decltype(dc)::value, q = d / IPS, i = d % IPS;
+        __builtin_amdgcn_global_load_lds((gptr_t)src[i][q], (lptr_t)(stage + q * SUB + (i * RPI + wave * 8) * 128), 16, 0, 0);
+    };
+
+    // ---- fragment roles ---------------------------------------------------------------------------------------------
+    const int wr = wave / WC, wc = wave % WC;                   // wave tile: 64 co x 64 columns
+    const int i16 = lane & 15, g = lane >> 4;
+    const int key = tr_key(i16), cg = tr_cg(i16), kb = g >> 1, chh = g & 1;
+    const int sw = (key >> 1) & 1;                              // pixel rows 2,3 (mod 4) keep their 64-byte halves swapped
+    uint32_t fo[4];                                             // A0 A1 B0 B1: byte offset of the fragment's first read in a stage
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int inrow = ((i ^ sw) << 6) + chh * 32 + cg * 8;
+        fo[i] = wr * SUB + (kb * 8 + key) * 128 + inrow;
+        fo[2 + i] = (NSA + wc) * SUB + (kb * 8 + key) * 128 + inrow;
+    }
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const uint32_t s0 = lds_addr(smem);
+    Frag fr[2][4];
+    auto rd = [&](auto setc, auto sc, auto rc, uint32_t sT) {     // read rc (fragment rc / 2, lo / hi half) of k-step sc
+        constexpr int set = decltype(setc)::value, S = decltype(sc)::value, r = decltype(rc)::value, f = r >> 1;
+        if constexpr (r & 1) tr_issue<S * 16 * 128 + 512>(fr[set][f].hi, sT + fo[f]);
+        else tr_issue<S * 16 * 128>(fr[set][f].lo, sT + fo[f]);
+    };
+    using I0 = std::integral_constant<int, 0>;
+
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) {
+        prep(c_begin + s);
+        static_for_n<GR>([&](auto dc) { dma(smem + s * STG, dc); });
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * GR) : "memory");
+    __builtin_amdgcn_s_barrier();
+    static_for_n<R>([&](auto rc) { rd(I0{}, I0{}, rc, s0); });
+    int rb = 0;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        prep(chunk + NST - 1);
+        const int wb = rb == 0 ? NST - 1 : rb - 1, nb = rb + 1 == NST ? 0 : rb + 1;
+        const uint32_t sT = s0 + rb * STG, sN = s0 + nb * STG;
+        char* stw = smem + wb * STG;
+        static_for_n<KS>([&](auto sc) {
+            constexpr int S = decltype(sc)::value, CUR = S & 1, NXT = CUR ^ 1;
+            if constexpr (S == KS - 1) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * GR) : "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            static_for_n<NM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value, i = m >> 1, j = m & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                Mma<BF16>::run(frag_vec(fr[CUR][i]), frag_vec(fr[CUR][2 + j]), acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int r_lo = m * R / NM, r_hi = (m + 1) * R / NM;
+                static_for_n<r_hi - r_lo>([&](auto k) {
+                    using RC = std::integral_constant<int, r_lo + decltype(k)::value>;
+                    if constexpr (S + 1 < KS) rd(std::integral_constant<int, NXT>{}, std::integral_constant<int, S + 1>{}, RC{}, sT);
+                    else rd(std::integral_constant<int, NXT>{}, I0{}, RC{}, sN);
+                });
+                if constexpr (S < KS - 1) {
+                    constexpr int d_lo = (S * NM + m) * GR / ((KS - 1) * NM), d_hi = (S * NM + m + 1) * GR / ((KS - 1) * NM);
+                    static_for_n<d_hi - d_lo>([&](auto k) { dma(stw, std::integral_constant<int, d_lo + decltype(k)::value>{}); });
+                }
+            });
+        });
+        rb = nb;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // zero-page tail groups, the last (unused) prefetch
+
+    // ---- epilogue: as conv_wgrad_tr ------------------------------------------------------------------------------------------
+    const size_t row_len = (size_t)a.Ttot * a.Ktot;
+    const int TK = a.T * a.Ktot;
+    const int frow = lane & 31, fk = lane >> 5;
+    const bool single = gridDim.y == 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = col_tile * TN + (wc * 2 + j) * 32 + frow;
+        const bool col_ok = col < TK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cb = co_tile * TM + (wr * 2 + i) * 32;             // first channel of the block (wave-uniform)
+            const int co0 = cb + 4 * fk;
+            float* p0 = a.dw + (size_t)co0 * row_len + (size_t)phase * TK + (col_ok ? col : 0);
+            if (single && cb + 32 <= a.Cout) {
+                if (col_ok) {
+                    float old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) old[r] = p0[(size_t)((r & 3) + 8 * (r >> 2)) * row_len];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p0[(size_t)((r & 3) + 8 * (r >> 2)) * row_len] = old[r] + acc[i][j][r];
+                }
+            } else if (col_ok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (co0 + dr >= a.Cout) continue;
+                    if (single) p0[(size_t)dr * row_len] += acc[i][j][r];
+                    else atomicAdd(p0 + (size_t)dr * row_len, acc[i][j][r]);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int launch_wgrad_tr(const ConvK& k0, hipStream_t st) {
     ConvK k = k0;
     if (k.Cout <= 64) return BTS_ERR_UNSUPPORTED;
     if ((long)k.N * k.Hy * k.Wy * k.dz_stride * 2 >= (1l << 32) || !segs_fit_u32(k)) return BTS_ERR_UNSUPPORTED;   // 32-bit byte offsets
+    k.nchunks = ceil_div(k.M, KC);
+    // BTS_WGRAD_TR: 1 = the two-stage 128 x 128 kernel of round 2 (A/B); 2 = the 128 x 256 three-stage ring [default]
+    static const int mode = [] { const char* e = getenv("BTS_WGRAD_TR"); return e ? atoi(e) : 2; }();
+    if (mode >= 2) {
+        constexpr int NST = 3, LDS = NST * 6 * SUB;
+        k.n_co_tiles = ceil_div(k.Cout, 128);
+        k.n_col_tiles = ceil_div((long)k.T * k.Ktot, 256);
+        const int tiles = k.n_co_tiles * k.n_col_tiles * k.nphase;
+        // one 144 KiB workgroup per CU; split over pixels only until the chip is full, >= 8 chunks per workgroup
+        static const int slots_env = [] { const char* e = getenv("BTS_WGRAD_RING_WGS"); return e ? atoi(e) : 0; }();
+        const int slots = slots_env > 0 ? slots_env : bts_cu_count();
+        int splits = slots / tiles;
+        if (splits > k.nchunks / 8) splits = k.nchunks / 8;
+        if (splits < 1) splits = 1;
+        k.chunks_per_split = ceil_div(k.nchunks, splits);
+        splits = ceil_div(k.nchunks, k.chunks_per_split);
+        static DynLdsCache lds_set;
+        if (ensure_dyn_lds((const void*)conv_wgrad_ring<2, 4, NST>, LDS, lds_set) != BTS_OK) return BTS_ERR_LAUNCH;
+        dim3 grid(k.n_co_tiles * k.n_col_tiles, splits, k.nphase);
+        hipLaunchKernelGGL((conv_wgrad_ring<2, 4, NST>), grid, dim3(512), (size_t)LDS, st, k);
+        if (hipGetLastError() != hipSuccess) return BTS_ERR_LAUNCH;
+        return BTS_OK;
+    }
     k.n_co_tiles = ceil_div(k.Cout, 128);
     k.n_col_tiles = ceil_div((long)k.T * k.Ktot, 128);
-    k.nchunks = ceil_div(k.M, KC);
     const int tiles = k.n_co_tiles * k.n_col_tiles * k.nphase;
     // Pixel split: only until the chip is full -- `slots` workgroups at a time (2 per CU: 64 KiB of LDS each).  conv5: 252
     // tiles -> 2 splits (one round of 105 chunks); layers with more tiles than slots are not split at all: a wave-quantisation

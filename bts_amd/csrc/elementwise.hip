@@ -347,6 +347,256 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
     }
 }
 
+
+// ---- BatchNorm over a channel CONCATENATION, one launch per BatchNorm (bts.py:51-66, 200-218) -------------------------------
+// The dense-ASPP first_bn layers normalise cat(up4, skip2, daspp_3, ...) -- 3 to 6 tensors that are never concatenated here.
+// Round 2 ran stats-final + prepare + affine per tensor per BatchNorm (28 segment launches per pass for 12 BatchNorms, each
+// 5-30 us for 14-80 MB: launch-floor bound).  These kernels take the whole concatenation as a segment table: blockIdx.y
+// selects (segment, channel-vector block), scale / shift are derived in registers from (mean, var, gamma, beta) -- the
+// `prepare` launch is gone -- and the running-statistics update is done by the first pixel block of each channel block.
+struct BnSegK {
+    const char* x;
+    char* dx;
+    const float* mean;
+    const float* var;
+    int CV, xs, dxs, acc;      // channel vectors, strides in elements, accumulate flag
+    int c0, by0;               // first channel of the segment in the concatenation, first blockIdx.y of the segment
+};
+struct BnK {
+    BnSegK seg[BTS_BN_MAX_SEG];
+    int nseg, bxl;
+    long M;
+    const float* gamma;
+    const float* beta;
+    float* rmean;
+    float* rvar;
+    float eps, momentum;
+    char* y;       // forward: normalised concatenation; backward: its gradient
+    int ys;
+    char* y2;      // forward, optional: relu(y)
+    int y2s;
+    int Ctot, use_batch;
+};
+
+// (segment of this block: chains of wave-uniform selects per field -- a dynamic index into the by-value argument, or an aggregate
+// copy of one entry, goes through scratch memory)
+__device__ __forceinline__ BnSegK bn_pick_seg(const BnK& k) {
+    BnSegK s;
+    s.x = k.seg[0].x; s.dx = k.seg[0].dx; s.mean = k.seg[0].mean; s.var = k.seg[0].var;
+    s.CV = k.seg[0].CV; s.xs = k.seg[0].xs; s.dxs = k.seg[0].dxs; s.acc = k.seg[0].acc; s.c0 = k.seg[0].c0; s.by0 = k.seg[0].by0;
+#pragma unroll
+    for (int i = 1; i < BTS_BN_MAX_SEG; ++i) {
+        const bool in = (int)blockIdx.y >= k.seg[i].by0;          // unused entries carry by0 = 2^30
+        s.x = in ? k.seg[i].x : s.x; s.dx = in ? k.seg[i].dx : s.dx;
+        s.mean = in ? k.seg[i].mean : s.mean; s.var = in ? k.seg[i].var : s.var;
+        s.CV = in ? k.seg[i].CV : s.CV; s.xs = in ? k.seg[i].xs : s.xs; s.dxs = in ? k.seg[i].dxs : s.dxs;
+        s.acc = in ? k.seg[i].acc : s.acc; s.c0 = in ? k.seg[i].c0 : s.c0; s.by0 = in ? k.seg[i].by0 : s.by0;
+    }
+    return s;
+}
+
+template <typename T, int U, bool RELU, bool DUAL>
+__global__ __launch_bounds__(256) void bn_apply_ms_kernel(const BnK k) {
+    constexpr int V = T::kVec;
+    const BnSegK sg = bn_pick_seg(k);
+    const int bx = 1 << k.bxl, tx = threadIdx.x & (bx - 1), ty = threadIdx.x >> k.bxl, by = 256 >> k.bxl;
+    const int cv = ((int)blockIdx.y - sg.by0) * bx + tx;
+    if (cv >= sg.CV) return;
+    long p = (long)blockIdx.x * by + ty;
+    const long ps = (long)gridDim.x * by;
+    float sc[V], sh[V];
+    {
+        float m[V], v[V], g[V], b[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {            // unconditional: all in flight together
+            const int c = cv * V + e;
+            m[e] = sg.mean[c]; v[e] = sg.var[c]; g[e] = k.gamma[sg.c0 + c]; b[e] = k.beta[sg.c0 + c];
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {            // bn_prepare_kernel's arithmetic, operation for operation
+            const float is = 1.f / sqrtf(v[e] + k.eps);
+            sc[e] = g[e] * is;
+            sh[e] = b[e] - m[e] * g[e] * is;
+        }
+        if (k.rmean && blockIdx.x == 0 && ty == 0) {      // nn.BatchNorm2d train mode: momentum update, unbiased variance
+            const double M = (double)k.M;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int c = sg.c0 + cv * V + e;
+                const float unb = M > 1.0 ? (float)((double)v[e] * (M / (M - 1.0))) : v[e];
+                k.rmean[c] = (1.f - k.momentum) * k.rmean[c] + k.momentum * m[e];
+                k.rvar[c] = (1.f - k.momentum) * k.rvar[c] + k.momentum * unb;
+            }
+        }
+    }
+    const char* xb = sg.x + (size_t)cv * 16;
+    char* yb = k.y + ((size_t)sg.c0 * T::kBytes + (size_t)cv * 16);
+    char* y2b = DUAL ? k.y2 + ((size_t)sg.c0 * T::kBytes + (size_t)cv * 16) : nullptr;
+    const size_t xst = (size_t)sg.xs * T::kBytes, yst = (size_t)k.ys * T::kBytes, y2st = (size_t)k.y2s * T::kBytes;
+    auto one = [&](const u32x4_t& v, long q) {
+        float f[V];
+        T::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float t = f[e] * sc[e] + sh[e];
+            f[e] = RELU ? fmaxf(t, 0.f) : t;
+        }
+        st16(yb, q, yst, T::pack(f));
+        if (DUAL) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) f[e] = fmaxf(f[e], 0.f);
+            st16(y2b, q, y2st, T::pack(f));
+        }
+    };
+    for (; p + (U - 1) * ps < k.M; p += U * ps) {
+        u32x4_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ld16(xb, p + u * ps, xst);
+        __builtin_amdgcn_sched_barrier(0);    // keep the whole batch of loads in front of their first use
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(v[u], p + u * ps);
+    }
+    for (; p < k.M; p += ps) one(ld16(xb, p, xst), p);
+}
+
+// block_partials_out for an arbitrary channel base
+template <int V>
+__device__ __forceinline__ void block_partials_out_at(const float* a, const float* b, int bxl, bool valid, int cbase,
+                                                      float* __restrict__ ws, int Cpad) {
+    __shared__ float red[256][2 * 8 + 1];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { red[threadIdx.x][e] = a[e]; red[threadIdx.x][8 + e] = b[e]; }
+    __syncthreads();
+    const int bx = 1 << bxl, by = 256 >> bxl;
+    if (threadIdx.x < bx && valid) {   // ty == 0 lanes
+        for (int e = 0; e < V; ++e) {
+            float sa = 0.f, sb = 0.f;
+            for (int t = 0; t < by; ++t) { sa += red[t * bx + threadIdx.x][e]; sb += red[t * bx + threadIdx.x][8 + e]; }
+            ws[((size_t)blockIdx.x * 2 + 0) * Cpad + cbase + e] = sa;
+            ws[((size_t)blockIdx.x * 2 + 1) * Cpad + cbase + e] = sb;
+        }
+    }
+}
+
+template <typename T, int U, bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_partial_ms_kernel(const BnK k, float* __restrict__ ws, int Cpad) {
+    constexpr int V = T::kVec;
+    const BnSegK sg = bn_pick_seg(k);
+    const int bx = 1 << k.bxl, tx = threadIdx.x & (bx - 1), ty = threadIdx.x >> k.bxl, by = 256 >> k.bxl;
+    const int cv = ((int)blockIdx.y - sg.by0) * bx + tx;
+    long p = (long)blockIdx.x * by + ty;
+    const long ps = (long)gridDim.x * by;
+    float a[V], b[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] = b[e] = 0.f;
+    if (cv < sg.CV) {
+        float mu[V], is[V], g[V], be[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int c = cv * V + e;
+            mu[e] = sg.mean[c]; is[e] = sg.var[c]; g[e] = k.gamma[sg.c0 + c]; be[e] = k.beta[sg.c0 + c];
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) is[e] = 1.f / sqrtf(is[e] + k.eps);
+        const char* xb = sg.x + (size_t)cv * 16;
+        const char* db = k.y + ((size_t)sg.c0 * T::kBytes + (size_t)cv * 16);
+        const size_t xst = (size_t)sg.xs * T::kBytes, dst = (size_t)k.ys * T::kBytes;
+        auto one = [&](const u32x4_t& vx, const u32x4_t& vd) {
+            float fx[V], fd[V];
+            T::unpack(vx, fx);
+            T::unpack(vd, fd);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float xh = (fx[e] - mu[e]) * is[e];
+                float d = fd[e];
+                if (RELU) d = (xh * g[e] + be[e] > 0.f) ? d : 0.f;
+                a[e] += d; b[e] += d * xh;
+            }
+        };
+        for (; p + (U - 1) * ps < k.M; p += U * ps) {
+            u32x4_t vx[U], vd[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { vx[u] = ld16(xb, p + u * ps, xst); vd[u] = ld16(db, p + u * ps, dst); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) one(vx[u], vd[u]);
+        }
+        for (; p < k.M; p += ps) one(ld16(xb, p, xst), ld16(db, p, dst));
+    }
+    block_partials_out_at<V>(a, b, k.bxl, cv < sg.CV, sg.c0 + cv * V, ws, Cpad);
+}
+
+// ELUX: x is the OUTPUT of an ELU (bts.py:74-79, 156-161) whose derivative is folded in: dz = dx * (x > 0 ? 1 : x + 1), so the
+// producing convolution's data / weight gradients start from this kernel's output and the separate ELU' pass is gone.
+template <typename T, int U, bool RELU, bool ELUX, bool ACC>
+__device__ __forceinline__ void bn_bwd_apply_loop(const BnK& k, const BnSegK& sg, int cv, long p, long ps,
+                                                  const float* mu, const float* is, const float* g, const float* be,
+                                                  const float* k0, const float* k1) {
+    constexpr int V = T::kVec;
+    const char* xb = sg.x + (size_t)cv * 16;
+    const char* db = k.y + ((size_t)sg.c0 * T::kBytes + (size_t)cv * 16);
+    char* ob = sg.dx + (size_t)cv * 16;
+    const size_t xst = (size_t)sg.xs * T::kBytes, dst = (size_t)k.ys * T::kBytes, ost = (size_t)sg.dxs * T::kBytes;
+    auto one = [&](const u32x4_t& vx, const u32x4_t& vd, const u32x4_t& vo, long q) {
+        float fx[V], fd[V], o[V];
+        T::unpack(vx, fx);
+        T::unpack(vd, fd);
+        if (ACC) T::unpack(vo, o);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float xh = (fx[e] - mu[e]) * is[e];
+            float d = fd[e];
+            if (RELU) d = (xh * g[e] + be[e] > 0.f) ? d : 0.f;
+            float r = g[e] * is[e] * (d - k0[e] - xh * k1[e]);
+            if (ELUX) r = fx[e] > 0.f ? r : r * (fx[e] + 1.f);
+            o[e] = ACC ? o[e] + r : r;
+        }
+        st16(ob, q, ost, T::pack(o));
+    };
+    for (; p + (U - 1) * ps < k.M; p += U * ps) {
+        u32x4_t vx[U], vd[U], vo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            vx[u] = ld16(xb, p + u * ps, xst);
+            vd[u] = ld16(db, p + u * ps, dst);
+            if (ACC) vo[u] = ld16(ob, p + u * ps, ost); else vo[u] = vx[u];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(vx[u], vd[u], vo[u], p + u * ps);
+    }
+    for (; p < k.M; p += ps) {
+        const u32x4_t vx = ld16(xb, p, xst);
+        one(vx, ld16(db, p, dst), ACC ? ld16(ob, p, ost) : vx, p);
+    }
+}
+
+template <typename T, int U, bool RELU, bool ELUX>
+__global__ __launch_bounds__(256) void bn_bwd_apply_ms_kernel(const BnK k, const float* __restrict__ sums) {
+    constexpr int V = T::kVec;
+    const BnSegK sg = bn_pick_seg(k);
+    const int bx = 1 << k.bxl, tx = threadIdx.x & (bx - 1), ty = threadIdx.x >> k.bxl, by = 256 >> k.bxl;
+    const int cv = ((int)blockIdx.y - sg.by0) * bx + tx;
+    if (cv >= sg.CV) return;
+    const long p = (long)blockIdx.x * by + ty, ps = (long)gridDim.x * by;
+    float mu[V], is[V], g[V], be[V], k0[V], k1[V];
+    const float invM = 1.f / (float)k.M;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const int c = cv * V + e;
+        mu[e] = sg.mean[c]; is[e] = sg.var[c]; g[e] = k.gamma[sg.c0 + c]; be[e] = k.beta[sg.c0 + c];
+        k0[e] = sums[sg.c0 + c]; k1[e] = sums[k.Ctot + sg.c0 + c];
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        is[e] = 1.f / sqrtf(is[e] + k.eps);
+        k0[e] = k.use_batch ? k0[e] * invM : 0.f;
+        k1[e] = k.use_batch ? k1[e] * invM : 0.f;
+    }
+    if (sg.acc) bn_bwd_apply_loop<T, U, RELU, ELUX, true>(k, sg, cv, p, ps, mu, is, g, be, k0, k1);   // wave-uniform branch
+    else bn_bwd_apply_loop<T, U, RELU, ELUX, false>(k, sg, cv, p, ps, mu, is, g, be, k0, k1);
+}
+
 // ---- activation backward (generic scalar indexing: also used for the 1-channel f32 maps) ---------
 template <typename TD, typename TY, typename TZ>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const void* __restrict__ dy, int dys, const void* __restrict__ y, int ys,
@@ -370,7 +620,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const void* __restrict__ d
 }
 
 // dz may alias dy (the decoder applies the activation derivative in place): no __restrict__ on those two
-template <typename T, int U>
+template <typename T, int U, bool ACC>
 __global__ __launch_bounds__(256) void act_bwd_vec_kernel(const void* dy, int dys, const void* __restrict__ y, int ys,
                                                           void* dz, int dzs, Shape2 s, int bxl, int act) {
     constexpr int V = T::kVec;
@@ -382,26 +632,34 @@ __global__ __launch_bounds__(256) void act_bwd_vec_kernel(const void* dy, int dy
     const char* yb = (const char*)y + (size_t)cv * 16;
     char* zb = (char*)dz + (size_t)cv * 16;
     const size_t dst = (size_t)dys * T::kBytes, yst = (size_t)ys * T::kBytes, zst = (size_t)dzs * T::kBytes;
-    auto one = [&](const u32x4_t& vd, const u32x4_t& vy, long q) {
-        float g[V], v[V];
+    auto one = [&](const u32x4_t& vd, const u32x4_t& vy, const u32x4_t& vo, long q) {
+        float g[V], v[V], o[V];
         T::unpack(vd, g);
         T::unpack(vy, v);
+        if (ACC) T::unpack(vo, o);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             const float neg = elu ? g[e] * (v[e] + 1.f) : 0.f;     // ELU'(z) = y + 1 for z <= 0 ; ReLU' = 0
             g[e] = v[e] > 0.f ? g[e] : neg;
+            if (ACC) g[e] += o[e];
         }
         st16(zb, q, zst, T::pack(g));
     };
     for (; p + (U - 1) * ps < s.M; p += U * ps) {
-        u32x4_t vd[U], vy[U];
+        u32x4_t vd[U], vy[U], vo[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { vd[u] = ld16(db, p + u * ps, dst); vy[u] = ld16(yb, p + u * ps, yst); }
+        for (int u = 0; u < U; ++u) {
+            vd[u] = ld16(db, p + u * ps, dst); vy[u] = ld16(yb, p + u * ps, yst);
+            if (ACC) vo[u] = ld16(zb, p + u * ps, zst); else vo[u] = vd[u];
+        }
         __builtin_amdgcn_sched_barrier(0);    // keep the whole batch of loads in front of their first use
 #pragma unroll
-        for (int u = 0; u < U; ++u) one(vd[u], vy[u], p + u * ps);
+        for (int u = 0; u < U; ++u) one(vd[u], vy[u], vo[u], p + u * ps);
     }
-    for (; p < s.M; p += ps) one(ld16(db, p, dst), ld16(yb, p, yst), p);
+    for (; p < s.M; p += ps) {
+        const u32x4_t vd = ld16(db, p, dst);
+        one(vd, ld16(yb, p, yst), ACC ? ld16(zb, p, zst) : vd, p);
+    }
 }
 
 template <typename TX, typename TY>
@@ -639,6 +897,114 @@ extern "C" int bts_affine_act(const void* x, int x_dtype, int x_stride, void* y,
     return BTS_OK;
 }
 
+
+// ---- multi-segment BatchNorm entry points ---------------------------------------------------------------------------------------
+static int bn_ms_setup(const bts_bn_desc_t* d, bool backward, BnK& k, int& gy) {
+    BTS_CHECK_ARG(d && d->nseg >= 1 && d->nseg <= BTS_BN_MAX_SEG && d->M > 0 && d->y && d->gamma && d->beta);
+    BTS_CHECK_ARG(d->dtype == BTS_F32 || d->dtype == BTS_BF16);
+    BTS_CHECK_ARG((d->running_mean == nullptr) == (d->running_var == nullptr));
+    const int V = d->dtype == BTS_F32 ? 4 : 8;
+    int ctot = 0, gcd = 0, cvmax = 0;
+    for (int i = 0; i < d->nseg; ++i) {
+        const bts_bn_seg_t& sg = d->seg[i];
+        BTS_CHECK_ARG(sg.x && sg.mean && sg.var && sg.C > 0 && vec_ok(d->dtype, sg.C, sg.x_stride, sg.x));
+        if (backward) BTS_CHECK_ARG(sg.dx && vec_ok(d->dtype, sg.C, sg.dx_stride, sg.dx));
+        const int cv = sg.C / V;
+        int a = cv, b = gcd;
+        while (b) { const int t = a % b; a = b; b = t; }
+        gcd = a;
+        cvmax = cv > cvmax ? cv : cvmax;
+        ctot += sg.C;
+    }
+    BTS_CHECK_ARG(d->y_stride >= ctot && d->y_stride % V == 0 && ((uintptr_t)d->y & 15) == 0);
+    if (!backward && d->y2) BTS_CHECK_ARG(d->y2_stride >= ctot && d->y2_stride % V == 0 && ((uintptr_t)d->y2 & 15) == 0);
+    // channel-vector lanes per block: the largest power of two <= 32 that divides every segment's vector count (no idle lanes);
+    // odd counts fall back to the single-tensor rule on the widest segment (guarded tails)
+    int bxl = 0;
+    while (bxl < 5 && gcd % (2 << bxl) == 0) ++bxl;
+    if ((1 << bxl) < 4) { bxl = 0; while ((1 << bxl) < cvmax && bxl < 5) ++bxl; }
+    const int bx = 1 << bxl;
+    k.nseg = d->nseg; k.bxl = bxl; k.M = d->M;
+    k.gamma = d->gamma; k.beta = d->beta; k.rmean = d->running_mean; k.rvar = d->running_var;
+    k.eps = d->eps; k.momentum = d->momentum;
+    k.y = (char*)d->y; k.ys = d->y_stride; k.y2 = (char*)d->y2; k.y2s = d->y2_stride;
+    k.Ctot = ctot; k.use_batch = d->use_batch_stats;
+    gy = 0;
+    int c0 = 0;
+    for (int i = 0; i < BTS_BN_MAX_SEG; ++i) {
+        BnSegK& o = k.seg[i];
+        if (i < d->nseg) {
+            const bts_bn_seg_t& sg = d->seg[i];
+            o.x = (const char*)sg.x; o.dx = (char*)sg.dx; o.mean = sg.mean; o.var = sg.var;
+            o.CV = sg.C / V; o.xs = sg.x_stride; o.dxs = sg.dx_stride; o.acc = sg.accumulate;
+            o.c0 = c0; o.by0 = gy;
+            gy += (o.CV + bx - 1) / bx;
+            c0 += sg.C;
+        } else {
+            o = BnSegK{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 1 << 30};
+        }
+    }
+    return BTS_OK;
+}
+
+// pixel-block count: `per` 16-byte vectors per thread, between one block per CU pair and max_blocks in total, <= max_rows
+static unsigned bn_ms_gx(long M, int gy, int bxl, int max_rows, long max_blocks) {
+    const int bx = 1 << bxl, by = 256 >> bxl;
+    long gx = (M + by - 1) / by;
+    const long want = (M * (long)gy * bx + 256l * g_vpt - 1) / (256l * g_vpt);
+    long blocks = want < 256 ? 256 : (want > max_blocks ? max_blocks : want);
+    long cap = blocks / gy > 0 ? blocks / gy : 1;
+    if (cap > max_rows) cap = max_rows;
+    if (gx > cap) gx = cap;
+    return (unsigned)(gx < 1 ? 1 : gx);
+}
+
+extern "C" int bts_bn_apply(const bts_bn_desc_t* d, bts_stream_t stream) {
+    BnK k; int gy;
+    const int rc = bn_ms_setup(d, false, k, gy);
+    if (rc != BTS_OK) return rc;
+    dim3 grid(bn_ms_gx(d->M, gy, k.bxl, 1 << 30, g_max_blocks), (unsigned)gy);
+    hipStream_t st = (hipStream_t)stream;
+#define L_(TT, RR, DD) hipLaunchKernelGGL((bn_apply_ms_kernel<TT, 4, RR, DD>), grid, dim3(256), 0, st, k)
+    if (d->relu) { if (d->y2) DISPATCH_T(d->dtype, L_, true, true); else DISPATCH_T(d->dtype, L_, true, false); }
+    else         { if (d->y2) DISPATCH_T(d->dtype, L_, false, true); else DISPATCH_T(d->dtype, L_, false, false); }
+#undef L_
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+static const int kBnBwdRows = 512;         // partial-sum rows of the backward reduction (bn_stats_final_kernel's input)
+static const long kBnBwdBlocks = 2048;     // ... and workgroups of its first pass
+
+extern "C" long bts_bn_bwd_workspace_bytes(const bts_bn_desc_t* d) {
+    if (!d) return 0;
+    long ctot = 0;
+    for (int i = 0; i < d->nseg && i < BTS_BN_MAX_SEG; ++i) ctot += d->seg[i].C;
+    const long Cpad = (ctot + 7) / 8 * 8;
+    return (long)kBnBwdRows * 2 * Cpad * (long)sizeof(float) + 64;
+}
+
+extern "C" int bts_bn_bwd(const bts_bn_desc_t* d, void* workspace, float* sums, bts_stream_t stream) {
+    BnK k; int gy;
+    const int rc = bn_ms_setup(d, true, k, gy);
+    if (rc != BTS_OK) return rc;
+    BTS_CHECK_ARG(workspace && sums);
+    const int Cpad = (k.Ctot + 7) / 8 * 8;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 gp(bn_ms_gx(d->M, gy, k.bxl, kBnBwdRows, kBnBwdBlocks), (unsigned)gy);
+#define L_(TT, RR) hipLaunchKernelGGL((bn_bwd_partial_ms_kernel<TT, 4, RR>), gp, dim3(256), 0, st, k, (float*)workspace, Cpad)
+    if (d->relu) DISPATCH_T(d->dtype, L_, true); else DISPATCH_T(d->dtype, L_, false);
+#undef L_
+    launch_stats_final((const float*)workspace, (int)gp.x, k.Ctot, Cpad, (double)d->M, 1, sums, sums + k.Ctot, st);
+    dim3 ga(bn_ms_gx(d->M, gy, k.bxl, 1 << 30, g_max_blocks), (unsigned)gy);
+#define L_(TT, RR, EE) hipLaunchKernelGGL((bn_bwd_apply_ms_kernel<TT, 4, RR, EE>), ga, dim3(256), 0, st, k, (const float*)sums)
+    if (d->relu) { if (d->elu_x) DISPATCH_T(d->dtype, L_, true, true); else DISPATCH_T(d->dtype, L_, true, false); }
+    else         { if (d->elu_x) DISPATCH_T(d->dtype, L_, false, true); else DISPATCH_T(d->dtype, L_, false, false); }
+#undef L_
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
 extern "C" int bts_bn_bwd_reduce(const void* dy, int dy_stride, const void* x, int x_stride, int dtype, long M, int C,
                                  const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
                                  void* workspace, float* sums, bts_stream_t stream) {
@@ -682,8 +1048,9 @@ extern "C" int bts_bn_bwd_apply(const void* dy, int dy_stride, const void* x, in
 
 extern "C" int bts_act_bwd(const void* dy, int dy_dtype, int dy_stride, const void* y, int y_dtype, int y_stride, void* dz,
                            int dz_dtype, int dz_stride, long M, int C, int act, float y_scale, const float* y_scale_n,
-                           long pix_per_image, bts_stream_t stream) {
+                           long pix_per_image, int accumulate, bts_stream_t stream) {
     BTS_CHECK_ARG(dy && y && dz && M > 0 && C > 0 && act >= BTS_ACT_NONE && act <= BTS_ACT_RELU);
+    BTS_CHECK_ARG(!accumulate || dz != dy);
     BTS_CHECK_ARG(y_scale_n == nullptr || pix_per_image > 0);
     hipStream_t st = (hipStream_t)stream;
     const bool same = dy_dtype == y_dtype && y_dtype == dz_dtype;
@@ -693,10 +1060,13 @@ extern "C" int bts_act_bwd(const void* dy, int dy_dtype, int dy_stride, const vo
         int bxl; dim3 grid;
         pick_grid(M, CV, bxl, grid);
         Shape2 s{M, CV};
-#define L_(TT, UU) hipLaunchKernelGGL((act_bwd_vec_kernel<TT, UU>), grid, dim3(256), 0, st, dy, dy_stride, y, y_stride, dz, dz_stride, s, bxl, act)
-        if (g_unroll4) DISPATCH_T(dy_dtype, L_, 4); else DISPATCH_T(dy_dtype, L_, 2);
+#define L_(TT, UU, AA) hipLaunchKernelGGL((act_bwd_vec_kernel<TT, UU, AA>), grid, dim3(256), 0, st, dy, dy_stride, y, y_stride, dz, dz_stride, s, bxl, act)
+#define LU_(TT, AA) do { if (g_unroll4) L_(TT, 4, AA); else L_(TT, 2, AA); } while (0)
+        if (accumulate) DISPATCH_T(dy_dtype, LU_, true); else DISPATCH_T(dy_dtype, LU_, false);
+#undef LU_
 #undef L_
     } else {
+        if (accumulate) return BTS_ERR_UNSUPPORTED;        // the scalar form (1-channel maps, mixed dtypes) only writes
         const int nb = flat_blocks(M * C);
         const int key = (dy_dtype << 2) | (y_dtype << 1) | dz_dtype;
 #define L3(A, B, Cc) hipLaunchKernelGGL((act_bwd_kernel<A, B, Cc>), dim3(nb), dim3(256), 0, st, dy, dy_stride, y, y_stride, dz, dz_stride, M, C, act, y_scale, y_scale_n, pix_per_image)

@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 from . import chain as chain_mod
-from . import ops
+from . import ops, profiler
 from ._lib import ACT_ELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BtsAmdError
 from .conv import ConvLayer
 from .ops import pad_to, vec_of
@@ -43,10 +43,11 @@ def reduction_specs(c_in, c_out, is_final):
 
 class Act:
     """An activation (NHWC tensor, or a single-channel f32 map [N,H,W]) and its gradient buffer."""
-    __slots__ = ("t", "g", "stats")
+    __slots__ = ("t", "g", "stats", "g_is_dz")
 
     def __init__(self, t):
         self.t, self.g, self.stats = t, None, None
+        self.g_is_dz = False      # set by a BatchNorm backward that folded this tensor's ELU derivative into what it wrote to g
 
 
 class DecoderPlan:
@@ -98,6 +99,10 @@ class DecoderPlan:
 
 def _cdiv(a, b):
     return (a + b - 1) // b
+
+
+def _esize(dtype):
+    return 4 if dtype == torch.float32 else 2
 
 
 class PackSet:
@@ -168,14 +173,20 @@ class PackSet:
         return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
 
     def pack_forward(self):
+        if profiler.ACTIVE is not None:
+            profiler.note("pack_weight_batch", "hbm", self.gw_total * 4 + sum(t.numel() for t in self.fwd.values()) * _esize(self.dtype))
         _lib.call("bts_pack_weight_batch", C.c_void_p(self.fjobs.data_ptr()), self.nf, self.fblocks, _lib.dtype_code(self.dtype),
                   _lib.stream_ptr())
 
     def pack_dgrad(self):
+        if profiler.ACTIVE is not None:
+            profiler.note("pack_weight_batch", "hbm", self.gw_total * 4 + sum(t.numel() for t in self.dgrad.values()) * _esize(self.dtype))
         _lib.call("bts_pack_weight_batch", C.c_void_p(self.djobs.data_ptr()), self.nd, self.dblocks, _lib.dtype_code(self.dtype),
                   _lib.stream_ptr())
 
     def unpack_all(self, dwp_arena, gw_arena):
+        if profiler.ACTIVE is not None:
+            profiler.note("unpack_wgrad_batch", "hbm", (self.dwp_total + self.gw_total) * 4)
         _lib.call("bts_unpack_wgrad_batch", C.c_void_p(self.ujobs.data_ptr()), self.nu, self.ublocks,
                   C.c_void_p(dwp_arena.data_ptr()), C.c_void_p(gw_arena.data_ptr()), _lib.stream_ptr())
 
@@ -235,7 +246,7 @@ class DecoderRun:
                 if out_map:
                     dz = ops.act_bwd(y.g, y.t, act, out_dtype=self.dtype, out_channels=self.v, y_scale=out_scale,
                                      y_scale_n=out_scale_n)
-                elif act == ACT_NONE:
+                elif act == ACT_NONE or y.g_is_dz:
                     dz = y.g
                 else:
                     dz = ops.act_bwd(y.g, y.t, act, out=y.g)
@@ -250,64 +261,76 @@ class DecoderRun:
             self.tape.append(bwd)
         return y
 
-    def _bn_params(self, prefix, c0, c1):
+    def bn(self, x, prefix, eps, relu=False, x_act=ACT_NONE, relu_copy=False):
+        return self.bn_cat([x], prefix, eps, relu, x_act, relu_copy)
+
+    def bn_cat(self, segs, prefix, eps, relu, x_act=ACT_NONE, relu_copy=False):
+        """BN(+ReLU) over the channel concatenation of `segs`, materialised as one tensor by ONE launch (csrc/elementwise.hip,
+        bn_apply_ms_kernel); its backward is one reduction + one apply launch for all segments.
+
+        x_act = ACT_ELU: the (single) input is the ELU output of a convolution that feeds nothing else (bts.py:199-208: upconv5,
+        upconv4, conv4, upconv3, upconv2); the backward then folds the ELU derivative into the gradient it writes, and the
+        producing convolution's backward starts from it (no separate activation-derivative pass).
+        relu_copy: also return relu(output) from the same launch (bts.py:208-210: bn4_2's output feeds daspp_conv as is and
+        daspp_3 through a ReLU)."""
         P = self.P
-        sl = slice(c0, c1)
-        return (P[prefix + ".weight"][sl], P[prefix + ".bias"][sl], P[prefix + ".running_mean"][sl],
-                P[prefix + ".running_var"][sl])
-
-    def _bn_seg(self, x, prefix, eps, relu, c0, out):
-        """BatchNorm (+ReLU) of one tensor against channels [c0, c0+C) of BN `prefix`; returns saved state."""
-        Cc = x.t.shape[3]
-        g, b, rm, rv = self._bn_params(prefix, c0, c0 + Cc)
-        M = ops.npix(x.t)
-        train = self.bn_training[prefix]
-        if train:
-            if x.stats is None:
-                x.stats = ops.bn_stats(x.t)      # shared by every BN that sees this tensor
-            mean, var = x.stats
-            invstd, scale, shift = ops.bn_prepare(mean, var, M, g, b, eps, BN_MOMENTUM, rm, rv)
-        else:
-            mean = rm
-            invstd, scale, shift = ops.bn_prepare(rm, rv, M, g, b, eps)
-        ops.affine_act(x.t, scale, shift, ACT_RELU if relu else ACT_NONE, out=out)
-        return mean, invstd, g, b, train
-
-    def bn(self, x, prefix, eps, relu=False):
-        return self.bn_cat([x], prefix, eps, relu)
-
-    def bn_cat(self, segs, prefix, eps, relu):
-        """BN(+ReLU) over the channel concatenation of `segs`, materialised as one tensor."""
         N, H, W, _ = segs[0].t.shape
         ctot = sum(s.t.shape[3] for s in segs)
-        out = torch.empty((N, H, W, ctot), dtype=self.dtype, device=segs[0].t.device)
-        saved, c0 = [], 0
+        dev = segs[0].t.device
+        train = self.bn_training[prefix]
+        g, b, rm, rv = P[prefix + ".weight"], P[prefix + ".bias"], P[prefix + ".running_mean"], P[prefix + ".running_var"]
+        if g.numel() != ctot:
+            raise BtsAmdError("BatchNorm %s has %d channels, its input %d" % (prefix, g.numel(), ctot))
+        stats, c0 = [], 0
         for s in segs:
             Cc = s.t.shape[3]
-            saved.append((s, c0, self._bn_seg(s, prefix, eps, relu, c0, out[..., c0:c0 + Cc])))
+            if train:
+                if s.stats is None:
+                    s.stats = ops.bn_stats(s.t)      # shared by every BN that sees this tensor
+                stats.append(s.stats)
+            else:
+                stats.append((rm[c0:c0 + Cc], rv[c0:c0 + Cc]))
             c0 += Cc
-        if any(st[4] for _, _, st in saved):
-            nbt = self.P.get(prefix + ".num_batches_tracked")
+        out = torch.empty((N, H, W, ctot), dtype=self.dtype, device=dev)
+        out2 = torch.empty_like(out) if relu_copy else None
+        ops.bn_apply([s.t for s in segs], stats, g, b, eps, relu, out, out2, BN_MOMENTUM if train else 0.0,
+                     rm if train else None, rv if train else None)
+        if train:
+            nbt = P.get(prefix + ".num_batches_tracked")
             if nbt is not None:
                 nbt.add_(1)
         y = Act(out)
+        y2 = Act(out2) if relu_copy else None
+        fold = x_act == ACT_ELU and len(segs) == 1
+        if x_act != ACT_NONE and not fold:
+            raise BtsAmdError("bn_cat: x_act is only supported for a single ELU input")
         if self.record:
             def bwd():
                 if y.g is None:
                     return
-                dgs, dbs = [], []
-                for s, c0, (mean, invstd, g, b, train) in saved:
-                    Cc = s.t.shape[3]
-                    acc = s.g is not None
-                    if not acc:
-                        s.g = torch.empty(s.t.shape, dtype=self.dtype, device=s.t.device)
-                    db, dg = ops.bn_bwd(y.g[..., c0:c0 + Cc], s.t, mean, invstd, g, b, relu, s.g, acc, train)
-                    dgs.append(dg)
-                    dbs.append(db)
-                self.grads[prefix + ".weight"] = torch.cat(dgs) if len(dgs) > 1 else dgs[0]
-                self.grads[prefix + ".bias"] = torch.cat(dbs) if len(dbs) > 1 else dbs[0]
+                accs = []
+                for s in segs:
+                    accs.append(s.g is not None)
+                    if s.g is None:
+                        s.g = torch.empty(s.t.shape, dtype=self.dtype, device=dev)
+                if fold:
+                    if accs[0]:
+                        raise BtsAmdError("bn_cat: ELU-folded input of %s has another consumer" % prefix)
+                    segs[0].g_is_dz = True
+                db, dg = ops.bn_bwd_ms(y.g, [s.t for s in segs], [s.g for s in segs], accs, stats, g, b, eps, relu, train, fold)
+                self.grads[prefix + ".weight"] = dg
+                self.grads[prefix + ".bias"] = db
             self.tape.append(bwd)
-        return y
+            if relu_copy:
+                def bwd2():
+                    if y2.g is None:
+                        return
+                    if y.g is None:
+                        y.g = ops.act_bwd(y2.g, y2.t, ACT_RELU)
+                    else:
+                        ops.act_bwd(y2.g, y2.t, ACT_RELU, out=y.g, accumulate=True)
+                self.tape.append(bwd2)
+        return (y, y2) if relu_copy else y
 
     def relu(self, x):
         y = Act(ops.affine_act(x.t, None, None, ACT_RELU))
@@ -318,7 +341,7 @@ class DecoderRun:
                 if x.g is None:
                     x.g = ops.act_bwd(y.g, y.t, ACT_RELU)
                 else:
-                    ops.add_to(ops.act_bwd(y.g, y.t, ACT_RELU, out=y.g), x.g, True)
+                    ops.act_bwd(y.g, y.t, ACT_RELU, out=x.g, accumulate=True)
             self.tape.append(bwd)
         return y
 
@@ -433,11 +456,11 @@ class DecoderRun:
         H, W = 2 * H2, 2 * W2
         s0, s1, s2, s3 = (self.feature(f[i]) for i in range(4))
         dense = self.feature(f[4], relu=True)                               # :198
-        u5 = self.bn(self.conv("upconv5.conv", [dense], ACT_ELU), "bn5", 1.1e-5)      # :199-200
+        u5 = self.bn(self.conv("upconv5.conv", [dense], ACT_ELU), "bn5", 1.1e-5, x_act=ACT_ELU)      # :199-200
         i5 = self.conv("conv5.0", [u5, s3], ACT_ELU)                        # :201-202
-        u4 = self.bn(self.conv("upconv4.conv", [i5], ACT_ELU), "bn4", 1.1e-5)        # :204-205
-        i4 = self.bn(self.conv("conv4.0", [u4, s2], ACT_ELU), "bn4_2", 1.1e-5)       # :206-208
-        d3 = self.atrous(3, self.relu(i4))                                  # :210 (no first_bn)
+        u4 = self.bn(self.conv("upconv4.conv", [i5], ACT_ELU), "bn4", 1.1e-5, x_act=ACT_ELU)        # :204-205
+        i4, i4r = self.bn(self.conv("conv4.0", [u4, s2], ACT_ELU), "bn4_2", 1.1e-5, x_act=ACT_ELU, relu_copy=True)   # :206-208
+        d3 = self.atrous(3, i4r)                                            # :210 (no first_bn; the ReLU of :58 comes with bn4_2)
         cat = [u4, s2, d3]
         dk = {3: d3}
         for d in (6, 12, 18, 24):                                           # :211-218
@@ -447,10 +470,10 @@ class DecoderRun:
         df = self.conv("daspp_conv.0", [i4, dk[3], dk[6], dk[12], dk[18], dk[24]], ACT_ELU)   # :219-220
 
         d8 = self.lpg_branch("reduc8x8", df, 8)                             # :222-228
-        u3 = self.bn(self.conv("upconv3.conv", [df], ACT_ELU), "bn3", 1.1e-5)        # :231-232
+        u3 = self.bn(self.conv("upconv3.conv", [df], ACT_ELU), "bn3", 1.1e-5, x_act=ACT_ELU)        # :231-232
         i3 = self.conv("conv3.0", [u3, s1, self.slots([d8], [4], N, H // 4, W // 4)], ACT_ELU)   # :229, 233-234
         d4 = self.lpg_branch("reduc4x4", i3, 4)                             # :236-242
-        u2 = self.bn(self.conv("upconv2.conv", [i3], ACT_ELU), "bn2", 1.1e-5)        # :245-246
+        u2 = self.bn(self.conv("upconv2.conv", [i3], ACT_ELU), "bn2", 1.1e-5, x_act=ACT_ELU)        # :245-246
         i2 = self.conv("conv2.0", [u2, s0, self.slots([d4], [2], N, H // 2, W // 2)], ACT_ELU)   # :243, 247-248
         d2 = self.lpg_branch("reduc2x2", i2, 2)                             # :250-256
         u1 = self.conv("upconv1.conv", [i2], ACT_ELU)                       # :258

@@ -90,6 +90,8 @@ def pack_maps(maps, ds, N, H, W, dtype):
     n = len(maps)
     src = (C.c_void_p * n)(*[m.data_ptr() for m in maps])
     dsa = (C.c_int * n)(*ds)
+    if profiler.ACTIVE is not None:
+        profiler.note("pack_maps", "hbm", N * H * W * (4 * n + Cp * dst.element_size()))
     call("bts_pack_maps", src, dsa, n, _p(dst), dtype_code(dtype), Cp, Cp, N, H, W, stream_ptr())
     return dst
 
@@ -100,6 +102,8 @@ def unpack_maps(gdst, gmaps, ds):
     n = len(gmaps)
     dst = (C.c_void_p * n)(*[m.data_ptr() for m in gmaps])
     dsa = (C.c_int * n)(*ds)
+    if profiler.ACTIVE is not None:
+        profiler.note("unpack_maps", "hbm", N * H * W * (8 * n + gdst.shape[3] * gdst.element_size()))
     call("bts_unpack_maps", _p(gdst), dtype_code(gdst.dtype), pix_stride(gdst), dst, dsa, n, N, H, W, stream_ptr())
 
 
@@ -112,6 +116,8 @@ def silog_fwd(est, gt, mask, variance_focus, gt_threshold=0.0):
     ws = torch.empty(call("bts_silog_workspace_bytes", n) // 8, dtype=torch.float64, device=est.device)
     stats = torch.empty(3, dtype=torch.float64, device=est.device)
     loss = torch.empty(1, dtype=torch.float32, device=est.device)
+    if profiler.ACTIVE is not None:       # est + gt (+ 1-byte mask) read once
+        profiler.note("silog_fwd", "hbm", n * (8 + (1 if mask is not None else 0)))
     call("bts_silog_fwd", _p(est), _p(gt), _p(mask), float(gt_threshold), n, float(variance_focus), _p(ws), _p(stats),
          _p(loss), stream_ptr())
     return loss, stats
@@ -119,6 +125,8 @@ def silog_fwd(est, gt, mask, variance_focus, gt_threshold=0.0):
 
 def silog_bwd(est, gt, mask, variance_focus, stats, loss, grad_loss, gt_threshold=0.0):
     g = torch.empty_like(est)
+    if profiler.ACTIVE is not None:
+        profiler.note("silog_bwd", "hbm", est.numel() * (12 + (1 if mask is not None else 0)))
     call("bts_silog_bwd", _p(est), _p(gt), _p(mask), float(gt_threshold), est.numel(), float(variance_focus), _p(stats),
          _p(loss), _p(grad_loss), _p(g), stream_ptr())
     return g
@@ -133,6 +141,8 @@ def nchw_to_nhwc(src, dtype, relu=False, c_pad=None):
     N, Cc, H, W = src.shape
     Cp = c_pad or Cc
     dst = (torch.zeros if Cp != Cc else torch.empty)((N, H, W, Cp), dtype=dtype, device=src.device)
+    if profiler.ACTIVE is not None:
+        profiler.note("nchw_to_nhwc", "hbm", N * Cc * H * W * (src.element_size() + dst.element_size()))
     call("bts_nchw_to_nhwc", _p(src), dtype_code(src.dtype), _p(dst), dtype_code(dtype), Cp, N, Cc, H, W, int(relu), stream_ptr())
     return dst
 
@@ -140,6 +150,8 @@ def nchw_to_nhwc(src, dtype, relu=False, c_pad=None):
 def nhwc_to_nchw(src, Cc, relu_src=None, out_dtype=torch.float32):
     N, H, W, _ = src.shape
     dst = torch.empty((N, Cc, H, W), dtype=out_dtype, device=src.device)
+    if profiler.ACTIVE is not None:
+        profiler.note("nhwc_to_nchw", "hbm", N * Cc * H * W * (src.element_size() + dst.element_size() * (2 if relu_src is not None else 1)))
     call("bts_nhwc_to_nchw", _p(src), dtype_code(src.dtype), pix_stride(src), _p(dst), dtype_code(out_dtype), _p(relu_src),
          N, Cc, H, W, stream_ptr())
     return dst
@@ -150,6 +162,8 @@ def bn_stats(x):
     ws = torch.empty(call("bts_bn_stats_workspace_bytes", M, Cc) // 4, dtype=torch.float32, device=x.device)
     mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
     var = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    if profiler.ACTIVE is not None:
+        profiler.note("bn_stats", "hbm", M * Cc * x.element_size())
     call("bts_bn_stats", _p(x), dtype_code(x.dtype), pix_stride(x), M, Cc, _p(ws), _p(mean), _p(var), stream_ptr())
     return mean, var
 
@@ -159,6 +173,8 @@ def bn_prepare(mean, var, M, gamma, beta, eps, momentum=0.0, running_mean=None, 
     invstd = torch.empty_like(mean)
     scale = torch.empty_like(mean)
     shift = torch.empty_like(mean)
+    if profiler.ACTIVE is not None:
+        profiler.note("bn_prepare", "hbm", Cc * 4 * 8)
     call("bts_bn_prepare", _p(mean), _p(var), Cc, M, _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
          _p(running_var), _p(invstd), _p(scale), _p(shift), stream_ptr())
     return invstd, scale, shift
@@ -167,6 +183,8 @@ def bn_prepare(mean, var, M, gamma, beta, eps, momentum=0.0, running_mean=None, 
 def affine_act(x, scale, shift, act, out=None):
     if out is None:
         out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    if profiler.ACTIVE is not None:
+        profiler.note("affine_act", "hbm", npix(x) * x.shape[3] * (x.element_size() + out.element_size()))
     call("bts_affine_act", _p(x), dtype_code(x.dtype), pix_stride(x), _p(out), dtype_code(out.dtype), pix_stride(out),
          npix(x), x.shape[3], _p(scale), _p(shift), act, stream_ptr())
     return out
@@ -177,15 +195,73 @@ def bn_bwd(dy, x, mean, invstd, gamma, beta, relu, dx, accumulate, use_batch_sta
     M, Cc = npix(x), x.shape[3]
     sums = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
     ws = torch.empty(call("bts_bn_stats_workspace_bytes", M, Cc) // 4, dtype=torch.float32, device=x.device)
+    if profiler.ACTIVE is not None:
+        profiler.note("bn_bwd_reduce", "hbm", M * Cc * x.element_size() * 2)
     call("bts_bn_bwd_reduce", _p(dy), pix_stride(dy), _p(x), pix_stride(x), dtype_code(x.dtype), M, Cc, _p(mean), _p(invstd),
          _p(gamma), _p(beta), int(relu), _p(ws), _p(sums), stream_ptr())
+    if profiler.ACTIVE is not None:
+        profiler.note("bn_bwd_apply", "hbm", M * Cc * x.element_size() * (4 if accumulate else 3))
     call("bts_bn_bwd_apply", _p(dy), pix_stride(dy), _p(x), pix_stride(x), _p(dx), pix_stride(dx), dtype_code(x.dtype), M, Cc,
          _p(mean), _p(invstd), _p(gamma), _p(beta), int(relu), _p(sums), int(use_batch_stats), int(accumulate), stream_ptr())
     return sums[0], sums[1]
 
 
-def act_bwd(dy, y, act, out=None, out_dtype=None, out_channels=None, y_scale=1.0, y_scale_n=None):
-    """dz = dy * act'(y).  dy/y may be NHWC [N,H,W,C] or single-channel maps [N,H,W]."""
+def _bn_desc(xs, stats, gamma, beta, eps, relu):
+    d = _lib.BnDesc()
+    d.dtype = dtype_code(xs[0].dtype)
+    d.nseg = len(xs)
+    d.M = npix(xs[0])
+    for i, (x, (mean, var)) in enumerate(zip(xs, stats)):
+        d.seg[i].x = x.data_ptr()
+        d.seg[i].mean, d.seg[i].var = mean.data_ptr(), var.data_ptr()
+        d.seg[i].C, d.seg[i].x_stride = x.shape[3], pix_stride(x)
+    d.gamma, d.beta = gamma.data_ptr(), beta.data_ptr()
+    d.eps = float(eps)
+    d.relu = int(bool(relu))
+    return d
+
+
+def bn_apply(xs, stats, gamma, beta, eps, relu, out, out2=None, momentum=0.0, running_mean=None, running_var=None):
+    """BatchNorm(+ReLU) of the channel concatenation of `xs` (NHWC tensors, same pixels) into `out` in ONE launch; `stats` holds
+    each tensor's (mean, var).  out2 (optional) receives relu(out).  running_*: train-mode update of the [sum C] buffers."""
+    if len(xs) > _lib.BN_MAX_SEG:
+        raise BtsAmdError("bn_apply: at most %d concatenated tensors" % _lib.BN_MAX_SEG)
+    _lib.require_gpu(xs[0])
+    d = _bn_desc(xs, stats, gamma, beta, eps, relu)
+    d.momentum = float(momentum)
+    d.running_mean = running_mean.data_ptr() if running_mean is not None else None
+    d.running_var = running_var.data_ptr() if running_var is not None else None
+    d.y, d.y_stride = out.data_ptr(), pix_stride(out)
+    if out2 is not None:
+        d.y2, d.y2_stride = out2.data_ptr(), pix_stride(out2)
+    if profiler.ACTIVE is not None:
+        ctot = sum(x.shape[3] for x in xs)
+        profiler.note("bn_apply", "hbm", npix(xs[0]) * ctot * xs[0].element_size() * (3 if out2 is not None else 2))
+    call("bts_bn_apply", C.byref(d), stream_ptr())
+    return out
+
+
+def bn_bwd_ms(dy, xs, dxs, accs, stats, gamma, beta, eps, relu, use_batch_stats, elu_x=False):
+    """Backward of bn_apply: dy = gradient of the normalised concatenation; dxs[i] (+)= gradient of xs[i]; returns
+    (dbeta, dgamma) over the concatenated channels.  elu_x: see include/bts_amd.h (ELU derivative of the producer folded in)."""
+    d = _bn_desc(xs, stats, gamma, beta, eps, relu)
+    for i, (dx, acc) in enumerate(zip(dxs, accs)):
+        d.seg[i].dx, d.seg[i].dx_stride, d.seg[i].accumulate = dx.data_ptr(), pix_stride(dx), int(bool(acc))
+    d.y, d.y_stride = dy.data_ptr(), pix_stride(dy)
+    d.use_batch_stats = int(bool(use_batch_stats))
+    d.elu_x = int(bool(elu_x))
+    ctot = sum(x.shape[3] for x in xs)
+    ws = torch.empty(call("bts_bn_bwd_workspace_bytes", C.byref(d)) // 4, dtype=torch.float32, device=dy.device)
+    sums = torch.empty((2, ctot), dtype=torch.float32, device=dy.device)
+    if profiler.ACTIVE is not None:      # reduction pass: dy + x; apply pass: dy + x read, dx written (+ read when accumulating)
+        es = xs[0].element_size()
+        profiler.note("bn_bwd", "hbm", npix(xs[0]) * es * sum(x.shape[3] * (6 if a else 5) for x, a in zip(xs, accs)))
+    call("bts_bn_bwd", C.byref(d), _p(ws), _p(sums), stream_ptr())
+    return sums[0], sums[1]
+
+
+def act_bwd(dy, y, act, out=None, out_dtype=None, out_channels=None, y_scale=1.0, y_scale_n=None, accumulate=False):
+    """dz (+)= dy * act'(y).  dy/y may be NHWC [N,H,W,C] or single-channel maps [N,H,W]."""
     if dy.dim() == 3:
         N, H, W = dy.shape
         Cc, dys, ys, M = 1, 1, 1, N * H * W
@@ -197,12 +273,16 @@ def act_bwd(dy, y, act, out=None, out_dtype=None, out_channels=None, y_scale=1.0
         if out is None:
             out = torch.empty(dy.shape, dtype=out_dtype or dy.dtype, device=dy.device)
     ppi = M // dy.shape[0]
+    if profiler.ACTIVE is not None:
+        profiler.note("act_bwd", "hbm", M * Cc * (dy.element_size() + y.element_size() + out.element_size() * (2 if accumulate else 1)))
     call("bts_act_bwd", _p(dy), dtype_code(dy.dtype), dys, _p(y), dtype_code(y.dtype), ys, _p(out), dtype_code(out.dtype),
-         pix_stride(out), M, Cc, act, float(y_scale), _p(y_scale_n), ppi, stream_ptr())
+         pix_stride(out), M, Cc, act, float(y_scale), _p(y_scale_n), ppi, int(bool(accumulate)), stream_ptr())
     return out
 
 
 def add_to(x, y, accumulate=True):
+    if profiler.ACTIVE is not None:
+        profiler.note("add_to", "hbm", npix(x) * x.shape[3] * (x.element_size() + y.element_size() * (2 if accumulate else 1)))
     call("bts_add_to", _p(x), dtype_code(x.dtype), pix_stride(x), _p(y), dtype_code(y.dtype), pix_stride(y), npix(x), x.shape[3],
          int(accumulate), stream_ptr())
     return y

@@ -24,6 +24,7 @@ import ctypes as C
 
 import torch
 
+from . import profiler
 from ._lib import BtsAmdError, call, stream_ptr
 
 _ROW = 8        # floats per group row (include/bts_amd.h: bts_adamw_advance)
@@ -150,6 +151,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdamW needs dense f32 parameters with identically laid out gradients")
             t = self._table(gi, plist)
             b1, b2 = g["betas"]
+            if profiler.ACTIVE is not None:      # p, g, m, v read; p, m, v written
+                profiler.note("adamw_step", "hbm", 28.0 * sum(p.numel() for p in plist))
             call("bts_adamw_step", C.c_void_p(t["params"].data_ptr()), C.c_void_p(t["grads"].data_ptr()),
                  C.c_void_p(t["m1"].data_ptr()), C.c_void_p(t["m2"].data_ptr()), C.c_void_p(t["sizes"].data_ptr()),
                  t["n"], t["max_size"], 0.0, float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), 1.0, 1.0,

@@ -16,13 +16,17 @@ exchange step of the hot path is the mean of the gradients across ranks, once pe
   compute of everything registered before it;
 * bucket size defaults to 64 MiB: on MI355X nodes the 8 GPUs are fully connected by point-to-point
   xGMI links (7 x ~153 GB/s per GPU), so per-message latency, not switch bandwidth, is what small
-  buckets pay for; ~47 M parameters (DenseNet161-BTS, 188 MB f32) become 3 large messages.
+  buckets pay for; ~47 M parameters (DenseNet161-BTS, 188 MB f32) become 3 large messages -- plus one
+  small one: the LAST bucket (the earliest encoder layers, whose gradients close the backward pass) is
+  capped at ``tail_bytes`` (8 MiB), because its exchange is the only one nothing can overlap with;
+* the mean costs no extra pass at the end of the step: ``ReduceOp.AVG`` where the backend has it (RCCL),
+  otherwise the bucket is scaled by 1/world when it is launched, i.e. under the rest of the backward pass.
 
 One synchronising backward per step (hooks count gradients down to zero); gradient accumulation uses
 ``no_sync()`` for the earlier micro-batches, and a stray second backward raises instead of racing the in-flight exchange.
 
-The mean is computed as SUM followed by one in-place scale of the flat bucket (ReduceOp.AVG is not
-available on the gloo backend used by the CPU tests).
+``launch_log`` records, for every bucket exchange launched from a hook, how many gradient hooks had fired by then: the
+tests use it to hold "the decoder bucket is on the wire before the encoder's backward has finished".
 """
 import contextlib
 
@@ -31,9 +35,13 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, reduce_single=False):
+    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, reduce_single=False, tail_bytes=8 << 20):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        backend = dist.get_backend(process_group) if dist.is_initialized() else ""
+        self.use_avg = backend == "nccl"        # RCCL averages in the collective; gloo has no ReduceOp.AVG
+        self.launch_log = []                    # (bucket index, gradient hooks fired so far) per hook-driven launch
+        self._fired = 0
         # reduce_single: issue the collectives even at world size 1 (exercises the RCCL path on a one-GPU box)
         self.collective = self.world > 1 or (reduce_single and dist.is_initialized())
         self.params = [p for p in params if p.requires_grad]
@@ -42,18 +50,23 @@ class GradAllReducer:
         self._works = []
         self._hooks = []
         self._defer = False
-        self._build(bucket_bytes)
+        self._build(bucket_bytes, tail_bytes)
 
-    def _build(self, bucket_bytes):
+    def _build(self, bucket_bytes, tail_bytes):
         cur, cur_bytes = [], 0
         groups = []
+        remaining = sum(p.numel() * p.element_size() for p in self.params)
+        in_tail = False
         for p in reversed(self.params):
             nb = p.numel() * p.element_size()
-            if cur and (cur_bytes + nb > bucket_bytes or p.dtype != cur[0].dtype or p.device != cur[0].device):
+            start_tail = not in_tail and remaining <= tail_bytes and remaining < bucket_bytes
+            if cur and (cur_bytes + nb > bucket_bytes or start_tail or p.dtype != cur[0].dtype or p.device != cur[0].device):
                 groups.append(cur)
                 cur, cur_bytes = [], 0
+            in_tail = in_tail or start_tail
             cur.append(p)
             cur_bytes += nb
+            remaining -= nb
         if cur:
             groups.append(cur)
         for bi, ps in enumerate(groups):
@@ -70,8 +83,10 @@ class GradAllReducer:
         def hook(param):
             if self._defer:                         # inside no_sync(): gradients only accumulate in the bucket
                 return
+            self._fired += 1
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
+                self.launch_log.append((bi, self._fired))
                 self._launch(bi)
             elif self._pending[bi] < 0:
                 raise RuntimeError(
@@ -93,11 +108,19 @@ class GradAllReducer:
     def _reset(self):
         self._pending = {bi: len(ps) for bi, (_, ps) in enumerate(self.buckets)}
         self._works = []
+        self._fired = 0
+        self.launch_log = []
 
     def _launch(self, bi):
         flat = self.buckets[bi][0]
         if self.collective:
-            self._works.append((bi, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+            if self.use_avg:
+                op = dist.ReduceOp.AVG
+            else:
+                op = dist.ReduceOp.SUM
+                if self.world > 1:
+                    flat.mul_(1.0 / self.world)       # pre-scale at launch time: hidden under the remaining backward
+            self._works.append((bi, dist.all_reduce(flat, op=op, group=self.group, async_op=True)))
 
     def zero_grad(self):
         """Zero the buckets in place (keeps param.grad views valid; replaces optimizer.zero_grad())."""
@@ -106,17 +129,14 @@ class GradAllReducer:
         self._reset()
 
     def finish(self):
-        """Call after loss.backward(): launches buckets whose parameters received no gradient this step,
-        waits for every exchange and turns the sums into means."""
+        """Call after loss.backward(): launches buckets whose parameters received no gradient this step and
+        waits for every exchange (the buckets then hold the means)."""
         for bi, n in self._pending.items():
             if n > 0:                      # unused parameters (e.g. ResNet fc.*): still exchange, grads are zero
                 self._pending[bi] = 0
                 self._launch(bi)
         for bi, w in self._works:
             w.wait()
-        if self.world > 1:
-            for flat, _ in self.buckets:
-                flat.mul_(1.0 / self.world)
         self._works = []
 
     def reduce_all(self):
@@ -131,9 +151,6 @@ class GradAllReducer:
             self._launch(bi)
         for bi, w in self._works:
             w.wait()
-        if self.world > 1:
-            for flat, _ in self.buckets:
-                flat.mul_(1.0 / self.world)
         self._works = []
 
     def remove(self):

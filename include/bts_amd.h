@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BTS_AMD_ABI_VERSION 1
+#define BTS_AMD_ABI_VERSION 2
 
 enum { BTS_F32 = 0, BTS_BF16 = 1 };
 enum { BTS_ACT_NONE = 0, BTS_ACT_ELU = 1, BTS_ACT_SIGMOID = 2, BTS_ACT_RELU = 3 };
@@ -268,10 +268,49 @@ int bts_bn_bwd_apply(const void* dy, int dy_stride, const void* x, int x_stride,
                      int dtype, long M, int C, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, int relu, const float* sums, int use_batch_stats, int accumulate,
                      bts_stream_t stream);
-/* dz = dy * act'(y) given the activation OUTPUT y (ELU: y>0 ? 1 : y+1; SIGMOID: y(1-y); RELU: y>0). */
+/* BatchNorm (+ReLU) over a channel CONCATENATION of up to BTS_BN_MAX_SEG tensors in one launch (bts.py:51-66: the dense-ASPP
+ * first_bn layers normalise cat(up4, skip2, daspp_3, ...); the tensors are never concatenated).  Segment s holds channels
+ * [c0_s, c0_s + C_s) of the BatchNorm, c0 = running sum of C.  Statistics come per tensor (bts_bn_stats: a tensor's statistics are
+ * computed once and shared by every BatchNorm that sees it); scale = gamma / sqrt(var + eps), shift = beta - mean * scale are formed
+ * in registers.
+ *   bts_bn_apply:  y[:, c0_s + c] = act(x_s[:, c] * scale + shift), act = ReLU when `relu`; optional second output y2 = relu(y)
+ *                  (bts.py:208-210: bn4_2's output feeds daspp_conv as is and daspp_3 through a ReLU).  Train mode: pass the batch
+ *                  statistics and running_mean / running_var [sum C] -- they receive the nn.BatchNorm2d update (momentum, unbiased
+ *                  variance); eval mode: pass the running-stat slices as mean / var and NULL running_*.
+ *   bts_bn_bwd:    y = the gradient w.r.t. the normalised concatenation.  sums[0][c] = dbeta, sums[1][c] = dgamma ([2][sum C]);
+ *                  dx_s (+)= the gradient w.r.t. x_s (training-mode formula when use_batch_stats, else gamma * invstd * dy).
+ *                  elu_x: x_s is the OUTPUT of an ELU and dx_s receives the gradient w.r.t. the ELU's INPUT (x > 0 ? 1 : x + 1
+ *                  folded in), so the producing convolution needs no separate activation-derivative pass.
+ *                  workspace >= bts_bn_bwd_workspace_bytes(d). */
+#define BTS_BN_MAX_SEG 6
+typedef struct {
+    const void* x;          /* NHWC tensor of this segment */
+    void* dx;               /* backward: gradient buffer of x (NULL in forward) */
+    const float* mean;      /* [C] */
+    const float* var;       /* [C] biased variance */
+    int32_t C, x_stride, dx_stride;
+    int32_t accumulate;     /* backward: dx += instead of dx = */
+} bts_bn_seg_t;
+typedef struct {
+    int32_t dtype, nseg;
+    int64_t M;              /* pixels */
+    bts_bn_seg_t seg[BTS_BN_MAX_SEG];
+    const float* gamma; const float* beta;          /* [sum C] */
+    float* running_mean; float* running_var;        /* [sum C] or NULL */
+    float eps, momentum;
+    int32_t relu, use_batch_stats;
+    void* y; int32_t y_stride;                      /* forward: output; backward: its gradient (read) */
+    int32_t elu_x;
+    void* y2; int32_t y2_stride;                    /* forward only, optional */
+} bts_bn_desc_t;
+int bts_bn_apply(const bts_bn_desc_t* d, bts_stream_t stream);
+long bts_bn_bwd_workspace_bytes(const bts_bn_desc_t* d);
+int bts_bn_bwd(const bts_bn_desc_t* d, void* workspace, float* sums, bts_stream_t stream);
+/* dz (+)= dy * act'(y) given the activation OUTPUT y (ELU: y>0 ? 1 : y+1; SIGMOID: y(1-y); RELU: y>0).  accumulate: only for the
+ * vector form (same dtype everywhere, ELU / RELU, 16-byte aligned channel vectors), dz != dy. */
 int bts_act_bwd(const void* dy, int dy_dtype, int dy_stride, const void* y, int y_dtype, int y_stride,
                 void* dz, int dz_dtype, int dz_stride, long M, int C, int act, float y_scale,
-                const float* y_scale_n, long pix_per_image, bts_stream_t stream);
+                const float* y_scale_n, long pix_per_image, int accumulate, bts_stream_t stream);
 /* y (+)= x for NHWC slices (gradient accumulation between differently-strided buffers). */
 int bts_add_to(const void* x, int x_dtype, int x_stride, void* y, int y_dtype, int y_stride, long M, int C,
                int accumulate, bts_stream_t stream);

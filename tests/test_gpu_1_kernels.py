@@ -263,6 +263,101 @@ def test_batchnorm_train_fwd_bwd(dt, relu, shape):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ["cat3_relu", "cat6_relu_acc", "single_elu_fold", "single_relu_copy", "odd_vectors"])
+@pytest.mark.parametrize("train", [True, False], ids=["train", "eval"])
+def test_batchnorm_concat_multi_segment(dt, case, train):
+    """bts_bn_apply / bts_bn_bwd: BatchNorm(+ReLU) over a channel concatenation in one launch (the dense-ASPP first_bn layers,
+    bts.py:51-66) against F.batch_norm autograd on the materialised torch.cat (CPU f32): output, running statistics, every
+    segment's input gradient (written or accumulated), dgamma / dbeta; with the producer's ELU derivative folded into the
+    gradient (x = ELU output of a convolution, bts.py:199-208) and with the extra relu(y) output of bn4_2 (bts.py:208-210)."""
+    from bts_amd import ops
+    gen = torch.Generator().manual_seed(23)
+    v = 4 if dt == torch.float32 else 8
+    tol = 1e-4 if dt == torch.float32 else 2e-2
+    N, H, W = 2, 37, 41
+    chans, relu, fold, copy, accs = {
+        "cat3_relu": ([64, 48, 32], True, False, False, [False, True, False]),
+        "cat6_relu_acc": ([64, 48, 32, 32, 32, 32], True, False, False, [True, True, False, False, True, False]),
+        "single_elu_fold": ([72], False, True, False, [False]),
+        "single_relu_copy": ([40], False, True, True, [False]),
+        "odd_vectors": ([24, 40], True, False, False, [False, False]),     # 3 / 5 (6 / 10) channel vectors: guarded tails
+    }[case]
+    ctot = sum(chans)
+    eps = 1.1e-5
+    zs = [(torch.randn(N, c, H, W, generator=gen) * 1.5 + 0.3) for c in chans]
+    if dt == torch.bfloat16:
+        zs = [z.to(dt).float() for z in zs]
+    g = torch.rand(ctot, generator=gen) + 0.5
+    b = torch.rand(ctot, generator=gen) - 0.5
+    rm, rv = torch.rand(ctot, generator=gen) - 0.5, torch.rand(ctot, generator=gen) + 0.5
+    # ---- reference: x = ELU(z) for the folded case (z is the convolution's accumulator), cat, batch_norm, relu
+    zr = [z.clone().requires_grad_(True) for z in zs]
+    xr = [F.elu(z) for z in zr] if fold else zr
+    if fold and dt == torch.bfloat16:      # the stored activation is the bf16-rounded ELU output
+        xr = [x + (x.detach().to(dt).float() - x.detach()) for x in xr]
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.batch_norm(torch.cat(xr, 1), rm_ref, rv_ref, gr, br, train, 0.01, eps)
+    if relu:
+        y = F.relu(y)
+    gy = torch.randn(y.shape, generator=gen)
+    obj = (y * gy).sum()
+    if copy:
+        gy2 = torch.randn(y.shape, generator=gen)
+        obj = obj + (F.relu(y) * gy2).sum()
+    obj.backward()
+    # ---- product
+    xt = [_nhwc(x.detach(), dt, v) for x in xr]
+    gd, bd, rmd, rvd = g.to(DEV), b.to(DEV), rm.to(DEV), rv.to(DEV)
+    if train:
+        stats = [ops.bn_stats(x) for x in xt]
+    else:
+        stats, c0 = [], 0
+        for c in chans:
+            stats.append((rmd[c0:c0 + c], rvd[c0:c0 + c]))
+            c0 += c
+    out = torch.empty(N, H, W, ctot, dtype=dt, device=DEV)
+    out2 = torch.empty_like(out) if copy else None
+    ops.bn_apply(xt, stats, gd, bd, eps, relu, out, out2, 0.01 if train else 0.0, rmd if train else None, rvd if train else None)
+    assert rel(out.float().permute(0, 3, 1, 2), y) < tol
+    if copy:
+        assert torch.equal(out2, torch.relu(out))
+    assert rel(rmd, rm_ref) < 1e-4 and rel(rvd, rv_ref) < 1e-4
+    dy = _nhwc(gy, dt, v)
+    if copy:      # the ReLU copy's backward accumulates into the gradient of y (decoder: act_bwd(..., accumulate=True))
+        from bts_amd._lib import ACT_RELU
+        ops.act_bwd(_nhwc(gy2, dt, v), out2, ACT_RELU, out=dy, accumulate=True)
+    bases = [torch.randn(x.shape, generator=gen).to(dt).to(DEV) if a else None for x, a in zip(xt, accs)]
+    dxs = [bs.clone() if a else torch.empty_like(x) for x, a, bs in zip(xt, accs, bases)]
+    db, dg = ops.bn_bwd_ms(dy, xt, dxs, accs, stats, gd, bd, eps, relu, train, fold)
+    c0 = 0
+    for i, (z, dx, a, bs) in enumerate(zip(zr, dxs, accs, bases)):
+        got = dx.float() - bs.float() if a else dx.float()
+        assert rel(got.permute(0, 3, 1, 2), z.grad) < tol * (10 if a else 5), (case, i)
+        c0 += z.shape[1]
+    assert rel(dg, gr.grad) < tol * 5 and rel(db, br.grad) < tol * 5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_act_bwd_accumulate(dt):
+    from bts_amd import ops
+    from bts_amd._lib import ACT_ELU, ACT_RELU, BtsAmdError
+    gen = torch.Generator().manual_seed(12)
+    N, H, W, C = 2, 53, 61, 40
+    y = torch.randn(N, H, W, C, generator=gen).to(dt).to(DEV)
+    gy = torch.randn(N, H, W, C, generator=gen).to(dt).to(DEV)
+    base = torch.randn(N, H, W, C, generator=gen).to(dt).to(DEV)
+    for act in (ACT_ELU, ACT_RELU):
+        yf, gf = y.float(), gy.float()
+        d = (gf * torch.where(yf > 0, torch.ones_like(yf), yf + 1.0)) if act == ACT_ELU else torch.where(yf > 0, gf, torch.zeros_like(gf))
+        acc = base.clone()
+        ops.act_bwd(gy, y, act, out=acc, accumulate=True)
+        assert torch.equal(acc, (d + base.float()).to(dt))
+    with pytest.raises(BtsAmdError):        # in-place accumulate is meaningless and refused
+        ops.act_bwd(gy, y, ACT_ELU, out=gy, accumulate=True)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_act_bwd_streaming(dt):
     """ELU' / ReLU' through the vector kernel, out of place and in place (the decoder's form), several pixels per thread."""
     from bts_amd import ops

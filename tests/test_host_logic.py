@@ -105,5 +105,17 @@ def test_profiler_labels_follow_dispatch():
     assert conv._wgrad_kernel(bf, 32, True, True, 8, 176, 608) == "conv_wgrad_halo_up<bf16>"
     assert conv._wgrad_kernel(f32, 32, True, False, 8, 352, 1216) == "conv_wgrad<f32,32x128k4>"
     assert conv._wgrad_kernel(bf, 32, True, False, 1, 32, 64) == "conv_wgrad<bf16,32x128k4>"      # < 256 tiles
-    assert conv._wgrad_kernel(bf, 512, True, False, 8, 22, 76) == "conv_wgrad_tr<bf16,128x128>"    # wide bf16: LDS-DMA + transposing reads
+    assert conv._wgrad_kernel(bf, 512, True, False, 8, 22, 76) == "conv_wgrad_ring<bf16,128x256>"  # wide bf16: LDS-DMA + transposing reads
     assert conv._wgrad_kernel(f32, 512, True, False, 8, 22, 76) == "conv_wgrad<f32,128x128>"
+
+
+def test_bench_synthetic_inputs_match_the_test_recipe():
+    """bench.py builds its batch with bts_amd.synth (no import from oracle/ on the product side); the recipe the tests use
+    (oracle/bts_oracle.py) must be the same data, bit for bit."""
+    from bts_amd import synth
+    from oracle import bts_oracle as O
+    for ds in ("kitti", "nyu"):
+        assert torch.equal(synth.synth_focal(7, ds), O.synth_focal(7, ds))
+        a = synth.synth_depth_gt(2, 32, 64, ds, torch.Generator().manual_seed(5))
+        b = O.synth_depth_gt(2, 32, 64, ds, torch.Generator().manual_seed(5))
+        assert torch.equal(a, b)

@@ -151,3 +151,100 @@ def test_single_process_noop():
     net(torch.randn(1, 3, 8, 8)).sum().backward()
     red.finish()
     assert all(p.grad is not None for p in net.parameters() if p.requires_grad)
+
+
+# ---- the shape of the real step: a decoder whose backward delivers ALL its parameter gradients at once ----------------------
+class _OneShotDecoder(torch.autograd.Function):
+    """Stand-in for bts_amd.model._DecoderFn (the HIP decoder is one autograd node: features + every decoder parameter in,
+    five maps out; its backward returns the ~110 parameter gradients together)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3):
+        ctx.save_for_backward(x, w1, w2, w3)
+        return torch.tanh(x * w1.view(1, -1, 1, 1)) * w2.view(1, -1, 1, 1) + w3.view(1, -1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w1, w2, w3 = ctx.saved_tensors
+        t = torch.tanh(x * w1.view(1, -1, 1, 1))
+        gw3 = g.sum((0, 2, 3))
+        gw2 = (g * t).sum((0, 2, 3))
+        gt = g * w2.view(1, -1, 1, 1) * (1 - t * t)
+        return gt * w1.view(1, -1, 1, 1), (gt * x).sum((0, 2, 3)), gw2, gw3
+
+
+class StepNet(nn.Module):
+    """Encoder registered FIRST (as BtsModel does, bts.py:323-327), four layers; one-shot decoder registered last."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1), nn.ReLU(),
+                                     nn.Conv2d(8, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1))
+        self.decoder = nn.ParameterList([nn.Parameter(torch.randn(8) * 0.5) for _ in range(3)])
+
+    def forward(self, x):
+        return _OneShotDecoder.apply(self.encoder(x), *self.decoder)
+
+
+def _step_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bts_amd.parallel import GradAllReducer, broadcast_parameters
+        torch.manual_seed(7 + rank)
+        net = StepNet()
+        broadcast_parameters(net)
+        ref = StepNet()
+        ref.load_state_dict(net.state_dict())
+        # buckets: decoder (3 x 8 floats) + the two last encoder layers (2336 B each) | the second layer | tail: the FIRST layer only
+        first = sum(p.numel() * 4 for p in net.encoder[0].parameters())
+        red = GradAllReducer(net.parameters(), bucket_bytes=5000, tail_bytes=first)
+        assert len(red.buckets) == 3, [len(b[1]) for b in red.buckets]
+        assert [id(p) for p in red.buckets[-1][1]] == [id(p) for p in reversed(list(net.encoder[0].parameters()))], "tail bucket"
+        n_dec = len(list(net.decoder.parameters()))
+        assert {id(p) for p in red.buckets[0][1][:n_dec]} == {id(p) for p in net.decoder.parameters()}
+        x = torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(rank))
+        red.zero_grad()
+        net(x).pow(2).mean().backward()
+        log = list(red.launch_log)
+        red.finish()
+        # every bucket was launched from a hook (none left for finish()); the bucket that holds the decoder went on the wire
+        # while encoder gradients were still outstanding -- its launch happened before the last hook of the step fired -- and
+        # the exchange that closes the step is the small tail bucket.  (The autograd engine does not promise the order in
+        # which the AccumulateGrad nodes of one backward node run relative to its successors, so only these are asserted.)
+        n_hooks = len(red.params)
+        assert sorted(b for b, _ in log) == list(range(len(red.buckets))), log
+        when = dict(log)
+        assert when[0] < n_hooks, log
+        assert log[-1] == (len(red.buckets) - 1, n_hooks), log
+        ddp = nn.parallel.DistributedDataParallel(ref)
+        ddp(x).pow(2).mean().backward()
+        for (n, p), (_, pr) in zip(net.named_parameters(), ref.named_parameters()):
+            assert torch.allclose(p.grad, pr.grad, rtol=1e-5, atol=1e-7), n
+        flat = torch.cat([b[0] for b in red.buckets])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], g) for g in gathered)
+        q.put((rank, "ok"))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_allreducer_one_shot_decoder_overlap_world2_gloo():
+    """The real step's gradient arrival order (one-shot decoder node, then the encoder layer by layer): the decoder bucket's
+    exchange is launched before the encoder backward has finished, the last bucket is the small tail, results equal DDP's."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_step_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res

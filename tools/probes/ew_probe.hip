@@ -155,7 +155,7 @@ static void check_all(int dt, const char* cfg) {
         void* d_z = inplace ? d_y : d_dx;
         z.to_dev(d_z);
         ref = z;
-        int rc = bts_act_bwd(inplace ? d_y : d_dy, dt, ys, d_x, dt, xs, d_z, dt, z.stride, M, C, act, 1.f, nullptr, 0, nullptr);
+        int rc = bts_act_bwd(inplace ? d_y : d_dy, dt, ys, d_x, dt, xs, d_z, dt, z.stride, M, C, act, 1.f, nullptr, 0, 0, nullptr);
         HIPCHECK(hipDeviceSynchronize());
         for (long p = 0; p < M; ++p)
             for (int c = 0; c < C; ++c) {
@@ -357,7 +357,7 @@ int main(int argc, char** argv) {
                 if (kOld) { if (&c != &ecfgs[0]) break; snprintf(cfg, sizeof cfg, "old"); }
                 set_cfg(c.vpt, c.maxb, c.partb, c.lanes, c.u4, 0);
                 emit("affine_act", M, C, cfg, mode, time_us([&] { bts_affine_act(PX.next(tb, rot), dt, C, PO.next(tb, rot), dt, C, M, C, t_g, t_b, BTS_ACT_RELU, nullptr); }), 2.0 * tb);
-                emit("act_bwd_elu", M, C, cfg, mode, time_us([&] { bts_act_bwd(PD.next(tb, rot), dt, C, PX.next(tb, rot), dt, C, PO.next(tb, rot), dt, C, M, C, BTS_ACT_ELU, 1.f, nullptr, 0, nullptr); }), 3.0 * tb);
+                emit("act_bwd_elu", M, C, cfg, mode, time_us([&] { bts_act_bwd(PD.next(tb, rot), dt, C, PX.next(tb, rot), dt, C, PO.next(tb, rot), dt, C, M, C, BTS_ACT_ELU, 1.f, nullptr, 0, 0, nullptr); }), 3.0 * tb);
                 emit("bn_bwd_apply_relu", M, C, cfg, mode, time_us([&] { bts_bn_bwd_apply(PD.next(tb, rot), C, PX.next(tb, rot), C, PO.next(tb, rot), C, dt, M, C, t_mean, t_is, t_g, t_b, 1, t_sums, 1, 0, nullptr); }), 3.0 * tb);
                 emit("bn_bwd_apply_relu_acc", M, C, cfg, mode, time_us([&] { bts_bn_bwd_apply(PD.next(tb, rot), C, PX.next(tb, rot), C, PO.next(tb, rot), C, dt, M, C, t_mean, t_is, t_g, t_b, 1, t_sums, 1, 1, nullptr); }), 4.0 * tb);
             }
