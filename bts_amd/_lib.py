@@ -39,6 +39,7 @@ class ConvDesc(C.Structure):
         ("y", C.c_void_p), ("y_dtype", C.c_int32), ("y_stride", C.c_int32),
         ("Hy", C.c_int32), ("Wy", C.c_int32), ("osc", C.c_int32), ("act", C.c_int32),
         ("out_scale", C.c_float), ("out_scale_n", C.c_void_p), ("accumulate", C.c_int32),
+        ("fold_elu_y", C.c_void_p), ("fold_elu_stride", C.c_int32),
     ]
 
 
@@ -82,8 +83,10 @@ SIGNATURES = {
     "bts_lpg_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "bts_lpg_head_fwd": [_p, _i, _p, _p, _i, _i, _i, _i, _f, _p],
     "bts_lpg_head_bwd": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "bts_plane_fwd": [_p, _i, _p, _l, _f, _p],
+    "bts_plane_bwd": [_p, _i, _p, _p, _i, _i, _i, _l, _f, _p],
     "bts_lpg_chain_fwd": [_p, _i, _i, _i, _i, _p, _i, _p, _l, _i, _i, _i, _f, _p],
-    "bts_lpg_chain_bwd": [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _i, _l, _i, _i, _i, _f, _p],
+    "bts_lpg_chain_bwd": [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _i, _p, _p, _i, _l, _i, _i, _i, _f, _p],
     "bts_pack_maps": [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "bts_unpack_maps": [_p, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     "bts_eval_workspace_bytes": [_i],
@@ -95,6 +98,8 @@ SIGNATURES = {
     "bts_silog_bwd": [_p, _p, _p, _f, _l, _f, _p, _p, _p, _p, _p],
     "bts_conv_fwd": [C.POINTER(ConvDesc), _p],
     "bts_conv_wgrad": [C.POINTER(ConvDesc), _p, _i, _p, _p],
+    "bts_conv3x3_c1_fwd": [_p, _i, _i, _i, _p, _p, _i, _i, _i, _f, _p, _p],
+    "bts_conv3x3_c1_dgrad": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _f, _p, _p],
     "bts_pack_weight": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p, _p],
     "bts_unpack_wgrad": [_p, _i, _i, _i, _p, _i, _i, _p, _p, _i, _p],
     "bts_pack_weight_batch": [_p, _i, _l, _i, _p],

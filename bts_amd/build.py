@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libbts_amd.so")
-SOURCES = ["conv_igemm.hip", "conv_wgrad_tr.hip", "conv_igemm_pp.hip", "conv_halo_wide.hip", "lpg.hip", "lpg_chain.hip", "elementwise.hip", "evalops.hip"]
+SOURCES = ["conv_igemm.hip", "conv_wgrad_tr.hip", "conv_igemm_pp.hip", "conv_halo_wide.hip", "conv_c1.hip", "lpg.hip", "lpg_chain.hip", "elementwise.hip", "evalops.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "lpg_math.h"), os.path.join(os.path.dirname(HERE), "include", "bts_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 

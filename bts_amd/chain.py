@@ -109,7 +109,7 @@ def pack_chain_t(weights, dtype):
     return torch.cat(parts).contiguous()
 
 
-def chain_bwd(x, frags, frags_t, c0, k, max_depth, grad_out, grad_x, accumulate, grad_w):
+def chain_bwd(x, frags, frags_t, c0, k, max_depth, grad_out, grad_x, accumulate, grad_w, x_is_elu_output=False):
     """Fused backward: grad_out f32 [N,h*k,w*k] (or [N,h,w] for k = 1) -> grad_x (NHWC like x, written or accumulated)
     and the packed f32 weight gradients `grad_w` (list of [Cout_l, ld_l] views, accumulated)."""
     N, h, w, _ = x.shape
@@ -121,7 +121,8 @@ def chain_bwd(x, frags, frags_t, c0, k, max_depth, grad_out, grad_x, accumulate,
                       N * h * w * (c0 * x.element_size() * (3 if accumulate else 2) + 4 * k * k))
     call("bts_lpg_chain_bwd", C.c_void_p(x.data_ptr()), dtype_code(x.dtype), pix_stride(x), c0, C.c_void_p(frags.data_ptr()),
          frags.numel(), C.c_void_p(frags_t.data_ptr()), frags_t.numel(), C.c_void_p(grad_out.data_ptr()),
-         C.c_void_p(grad_x.data_ptr()), pix_stride(grad_x), int(bool(accumulate)), ptrs, lds, n, N * h * w, h, w, k,
+         C.c_void_p(grad_x.data_ptr()), pix_stride(grad_x), int(bool(accumulate)), int(bool(x_is_elu_output)), ptrs, lds, n,
+         N * h * w, h, w, k,
          float(max_depth), stream_ptr())
 
 

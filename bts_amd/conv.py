@@ -78,7 +78,7 @@ def _wide_pays(cout, n, hg, wg):
     wgs = ntiles * nco
     rounds = _cdiv(wgs, cus)
     fill = (hg * wg * n / (ntiles * 256.0)) * (cout / (nco * 128.0)) * (wgs / float(rounds * cus))
-    return fill >= 0.70
+    return fill >= float(os.environ.get("BTS_WIDE_FILL", "0.60"))
 
 
 _CONV_BIG_DEFAULT = "t"      # launch_fwd()'s default schedule letter (csrc/conv_igemm.hip)
@@ -98,14 +98,20 @@ def _fwd_kernel(dtype, cout, halo, geom=None, kv=8, up=False):
     return "conv_igemm_dma<%s,%s>" % (_dn(dtype), "128x128" if cout > 64 else ("64x128" if cout > 32 else "32x256"))
 
 
-def _wgrad_kernel(dtype, cout, radius1, up, n, hg, wg):
-    """Mirrors launch_wgrad()."""
+def _wgrad_kernel(dtype, cout, radius1, up, n, hg, wg, cols=None):
+    """Mirrors launch_wgrad() / launch_wgrad_tr().  cols = taps per phase x padded input channels (T * Ktot)."""
     if radius1 and not up and cout == 1:
         return "conv_wgrad_c1<%s>" % _dn(dtype)
+    if 32 < cout <= 64 and dtype == torch.bfloat16 and os.environ.get("BTS_WGRAD_RING64", "1") != "0":
+        return "conv_wgrad_ring<bf16,64x256>"
     if radius1 and cout <= 64 and dtype == torch.bfloat16 and _cdiv(wg, 32) * _cdiv(hg, 8) * n >= 256:
         return "conv_wgrad_halo_up<bf16>" if up else "conv_wgrad_halo<bf16>"
     if cout > 64 and dtype == torch.bfloat16 and os.environ.get("BTS_WGRAD_TR", "2")[:1] != "0":
-        return "conv_wgrad_tr<bf16,128x128>" if os.environ.get("BTS_WGRAD_TR", "2")[:1] == "1" else "conv_wgrad_ring<bf16,128x256>"
+        mode = os.environ.get("BTS_WGRAD_TR", "2")[:1]
+        ring_tiles = _cdiv(cout, 128) * _cdiv(cols if cols is not None else 256, 256) * (4 if up else 1)
+        if mode == "3" or (mode != "1" and ring_tiles <= 2 * _cu_count()):
+            return "conv_wgrad_ring<bf16,128x256>"
+        return "conv_wgrad_tr<bf16,128x128>"
     return "conv_wgrad<%s,%s>" % (_dn(dtype), "128x128" if cout > 64 else ("64x128k2" if cout > 32 else "32x128k4"))
 
 
@@ -230,8 +236,10 @@ class ConvLayer:
         else:
             d.y_stride, d.Hy, d.Wy = pix_stride(out), out.shape[1], out.shape[2]
 
-    def dgrad(self, dz, wd, seg_index, gx, accumulate):
-        """gx (+)= data-gradient w.r.t. input segment seg_index.  dz: NHWC [N,Ho,Wo,Cout_pad]."""
+    def dgrad(self, dz, wd, seg_index, gx, accumulate, fold_elu_y=None):
+        """gx (+)= data-gradient w.r.t. input segment seg_index.  dz: NHWC [N,Ho,Wo,Cout_pad].
+        fold_elu_y: that segment's forward tensor when it is an ELU output whose gradient this launch completes: the stored
+        value is (gx [+ old]) * ELU'(fold_elu_y) (include/bts_amd.h: bts_conv_desc_t::fold_elu_y)."""
         dtype = dz.dtype
         N = gx.shape[0]
         Hg, Wg = gx.shape[1], gx.shape[2]
@@ -252,6 +260,10 @@ class ConvLayer:
         d.out_scale = 1.0
         d.out_scale_n = None
         d.accumulate = int(accumulate)
+        if fold_elu_y is not None:
+            if fold_elu_y.shape != gx.shape or fold_elu_y.dtype != gx.dtype:
+                raise _lib.BtsAmdError("dgrad: fold_elu_y must have the gradient's shape and dtype")
+            d.fold_elu_y, d.fold_elu_stride = fold_elu_y.data_ptr(), pix_stride(fold_elu_y)
         if profiler.ACTIVE is not None:
             cseg = self.seg_channels[seg_index]
             profiler.note(_fwd_kernel(dtype, gx.shape[3], self.kk == 9 and self.dil == 1 and not self.up, (N, Hg, Wg),
@@ -273,7 +285,8 @@ class ConvLayer:
         d.Hy, d.Wy = dz.shape[1], dz.shape[2]
         d.osc = 2 if self.up else 1
         if profiler.ACTIVE is not None:
-            profiler.note(_wgrad_kernel(dtype, self.cout, self.kk == 9 and self.dil == 1, self.up, N, Hx, Wx), "mfma",
+            cols = self.T * sum(pad_to(c, vec_of(dtype)) for c in self.seg_channels)
+            profiler.note(_wgrad_kernel(dtype, self.cout, self.kk == 9 and self.dil == 1, self.up, N, Hx, Wx, cols), "mfma",
                           2.0 * N * Hx * Wx * self.nphase * self.T * self.cin * self.cout, self.name + ".wgrad")
         call("bts_conv_wgrad", C.byref(d), C.c_void_p(dz.data_ptr()), pix_stride(dz), C.c_void_p(dwp.data_ptr()), stream_ptr())
         return dwp

@@ -43,8 +43,11 @@ struct ConvK {
     int Cout, Ktot;
     char* y;
     int y_stride, Hy, Wy, osc, y_f32, act, accumulate, vec_store;
+    int wide_store;                // bf16 output rows (and fold_y rows) are 16-byte aligned: 32-channel blocks go out as 16-byte stores
     float out_scale;
     const float* out_scale_n;
+    const char* fold_y;            // data-gradient: multiply the stored value by ELU'(fold_y[pixel][co]) (ELU output), or nullptr
+    int fold_stride;               // pixel stride of fold_y in elements (dtype = y's)
     int n_px_tiles, n_co_tiles;
     // wgrad only
     const char* dz;
@@ -148,6 +151,160 @@ static __device__ const uint32_t kZeroPage[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// ELU'(z) from the ELU OUTPUT v (bts.py: nn.ELU, alpha = 1): the factor a completed gradient w.r.t. v is taken through the ELU with
+__device__ __forceinline__ float elu_dfac(float v) { return v > 0.f ? 1.f : v + 1.f; }
+// the 4 factors of channels [co, co+4) of pixel `opix` (vector form: fold_y is 8 / 16-byte aligned like y)
+__device__ __forceinline__ void fold_factors4(const ConvK& a, size_t opix, int co, float (&f)[4]) {
+    const size_t o = opix * (size_t)a.fold_stride + co;
+    if (a.y_f32) {
+        const f32x4_t v = *(const f32x4_t*)((const float*)a.fold_y + o);
+        f[0] = elu_dfac(v.x); f[1] = elu_dfac(v.y); f[2] = elu_dfac(v.z); f[3] = elu_dfac(v.w);
+    } else {
+        const u32x2_t v = *(const u32x2_t*)((const uint16_t*)a.fold_y + o);
+        f[0] = elu_dfac(__uint_as_float(v.x << 16)); f[1] = elu_dfac(__uint_as_float(v.x & 0xffff0000u));
+        f[2] = elu_dfac(__uint_as_float(v.y << 16)); f[3] = elu_dfac(__uint_as_float(v.y & 0xffff0000u));
+    }
+}
+__device__ __forceinline__ float fold_factor1(const ConvK& a, size_t opix, int co) {
+    const size_t o = opix * (size_t)a.fold_stride + co;
+    return elu_dfac(a.y_f32 ? ((const float*)a.fold_y)[o] : bf16_bits_to_f32(((const uint16_t*)a.fold_y)[o]));
+}
+
+// Store channels [co, co+4) of output pixel `opix`: optional accumulation into what is there, optional ELU-derivative fold
+// (ConvK::fold_y), vector form when the layout allows it.  Shared by the epilogues of conv_igemm*, conv_halo and conv_halo_wide.
+__device__ __forceinline__ void store_quad(const ConvK& a, size_t opix, int co, float (&v)[4]) {
+    const size_t o = opix * a.y_stride + co;
+    if (a.vec_store) {
+        float ff[4];
+        if (a.fold_y) fold_factors4(a, opix, co, ff);
+        if (a.y_f32) {
+            float* p = (float*)a.y + o;
+            f32x4_t t = {v[0], v[1], v[2], v[3]};
+            if (a.accumulate) { f32x4_t old = *(f32x4_t*)p; t += old; }
+            if (a.fold_y) { t[0] *= ff[0]; t[1] *= ff[1]; t[2] *= ff[2]; t[3] *= ff[3]; }
+            *(f32x4_t*)p = t;
+        } else {
+            uint16_t* p = (uint16_t*)a.y + o;
+            if (a.accumulate) {
+                u32x2_t old = *(u32x2_t*)p;
+                v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+            }
+            if (a.fold_y) { v[0] *= ff[0]; v[1] *= ff[1]; v[2] *= ff[2]; v[3] *= ff[3]; }
+            u32x2_t t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *(u32x2_t*)p = t;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (co + e >= a.Cout) break;
+            const float f = a.fold_y ? fold_factor1(a, opix, co + e) : 1.f;
+            if (a.y_f32) {
+                float* p = (float*)a.y + o + e;
+                *p = (a.accumulate ? *p + v[e] : v[e]) * f;
+            } else {
+                uint16_t* p = (uint16_t*)a.y + o + e;
+                const float t = (a.accumulate ? bf16_bits_to_f32(*p) + v[e] : v[e]) * f;
+                *p = (uint16_t)f32_to_bf16_bits(t);
+            }
+        }
+    }
+}
+
+// One 32-channel block [cb, cb+32) of output pixel `opix`, as the 32x32 MFMA leaves it: lane half fk holds channels
+// cb + 8q + 4fk + {0..3} in v[4q .. 4q+3] (already through activation and scale).
+//
+// bf16 outputs.  Written quad by quad, a lane stores 4 x 8 bytes at a 16-byte pitch and the two half-waves interleave inside every
+// 16 bytes: twice the store (and, when accumulating / folding, load) instructions of the bytes moved, each touching half-used
+// 16-byte slots of 32 different lines.  v_permlane32_swap exchanges the upper half-wave's quad 2p with the lower half-wave's quad
+// 2p+1 (cdna_hip_programming.md T21), after which a lane owns 8 CONSECUTIVE channels: cb + 8(2p + fk) + {0..7} -- one 16-byte
+// access per pair.  Accumulating / folding launches swap the f32 values (8 swaps per pair) so that the old value and the ELU
+// output are fetched in the same 16-byte form and the sum is still rounded once; plain launches swap the packed words (2 swaps).
+// f32 outputs already move 16 bytes per quad; all loads of a block are issued together in front of the stores either way
+// (hipcc otherwise serialises load / s_waitcnt vmcnt(0) / store per vector: it cannot prove the addresses distinct).
+// Blocks that straddle Cout, and unaligned layouts, go quad by quad (store_quad).
+__device__ __forceinline__ void store_block32(const ConvK& a, size_t opix, int cb, int fk, float (&v)[16]) {
+    if (a.vec_store && cb + 32 <= a.Cout && (a.y_f32 || a.wide_store)) {          // wave-uniform
+        if (a.y_f32) {
+            const size_t o0 = opix * a.y_stride + cb + 4 * fk;
+            f32x4_t oldv[4];
+            float ff[4][4];
+            if (a.accumulate) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) oldv[q] = *(const f32x4_t*)((const float*)a.y + o0 + 8 * q);
+            }
+            if (a.fold_y) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fold_factors4(a, opix, cb + 4 * fk + 8 * q, ff[q]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4_t t = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                if (a.accumulate) t += oldv[q];
+                if (a.fold_y) { t[0] *= ff[q][0]; t[1] *= ff[q][1]; t[2] *= ff[q][2]; t[3] *= ff[q][3]; }
+                *(f32x4_t*)((float*)a.y + o0 + 8 * q) = t;
+            }
+            return;
+        }
+        const bool rmw = a.accumulate || a.fold_y;
+        if (rmw) {
+            u32x4_t oldw[2], yw[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int co = cb + 8 * (2 * p + fk);
+                if (a.accumulate) oldw[p] = *(const u32x4_t*)((const uint16_t*)a.y + opix * a.y_stride + co);
+                if (a.fold_y) yw[p] = *(const u32x4_t*)((const uint16_t*)a.fold_y + opix * (size_t)a.fold_stride + co);
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 * p + e]), __float_as_uint(v[8 * p + 4 + e]), false, false);
+                    v[8 * p + e] = __uint_as_float(r[0]);
+                    v[8 * p + 4 + e] = __uint_as_float(r[1]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float t[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = v[8 * p + e];
+                if (a.accumulate) {
+                    float o[8];
+                    BF16::unpack(oldw[p], o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] += o[e];
+                }
+                if (a.fold_y) {
+                    float y[8];
+                    BF16::unpack(yw[p], y);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] *= elu_dfac(y[e]);
+                }
+                *(u32x4_t*)((uint16_t*)a.y + opix * a.y_stride + cb + 8 * (2 * p + fk)) = BF16::pack(t);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                uint32_t a0 = pack_bf16x2(v[8 * p], v[8 * p + 1]), a1 = pack_bf16x2(v[8 * p + 2], v[8 * p + 3]);
+                uint32_t b0 = pack_bf16x2(v[8 * p + 4], v[8 * p + 5]), b1 = pack_bf16x2(v[8 * p + 6], v[8 * p + 7]);
+                const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                *(u32x4_t*)((uint16_t*)a.y + opix * a.y_stride + cb + 8 * (2 * p + fk)) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int co = cb + 8 * q + 4 * fk;
+        if (co >= a.Cout) continue;
+        float t[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        store_quad(a, opix, co, t);
+    }
+}
+
 template <typename T, int WR, int WC, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16_t (&acc)[TM][TN], int co_tile, int px_tile, int phase,
                                               int wr, int wc, int frow, int fk) {
@@ -166,88 +323,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16_t (&acc)[TM
         if (a.out_scale_n) sc *= a.out_scale_n[n];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            // accumulate form of a 32-channel block that lies entirely inside Cout (wave-uniform test): the four old vectors are
-            // fetched together, pinned in front of the stores, and nothing in between is predicated.  In the general loop below
-            // hipcc serialises load / s_waitcnt vmcnt(0) / add / store per vector (it cannot prove the addresses distinct, and
-            // every predicated block waits for the previous store: on gfx9 vmcnt counts stores too).
             const int cb = co_tile * BM + (wr * TM + i) * 32;
-            if (a.accumulate && a.vec_store && cb + 32 <= a.Cout) {
-                const size_t o0 = opix * a.y_stride + cb + 4 * fk;
-                f32x4_t oldv[4];
-                if (a.y_f32) {
+            float v[16];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) oldv[q] = *(const f32x4_t*)((const float*)a.y + o0 + 8 * q);
-                } else {
-                    u32x2_t h[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) h[q] = *(const u32x2_t*)((const uint16_t*)a.y + o0 + 8 * q);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        oldv[q] = f32x4_t{__uint_as_float(h[q].x << 16), __uint_as_float(h[q].x & 0xffff0000u),
-                                          __uint_as_float(h[q].y << 16), __uint_as_float(h[q].y & 0xffff0000u)};
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4_t t;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float u = acc[i][j][4 * q + e];
-                        if (a.act == BTS_ACT_ELU) u = act_elu(u);
-                        else if (a.act == BTS_ACT_SIGMOID) u = act_sigmoid(u);
-                        else if (a.act == BTS_ACT_RELU) u = fmaxf(u, 0.f);
-                        t[e] = u * sc + oldv[q][e];
-                    }
-                    if (a.y_f32) *(f32x4_t*)((float*)a.y + o0 + 8 * q) = t;
-                    else *(u32x2_t*)((uint16_t*)a.y + o0 + 8 * q) = u32x2_t{pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
-                }
-                continue;
+            for (int r = 0; r < 16; ++r) {
+                float t = acc[i][j][r];
+                if (a.act == BTS_ACT_ELU) t = act_elu(t);
+                else if (a.act == BTS_ACT_SIGMOID) t = act_sigmoid(t);
+                else if (a.act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
+                v[r] = t * sc;
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int co = co_tile * BM + (wr * TM + i) * 32 + 8 * q + 4 * fk;
-                if (co >= a.Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[i][j][4 * q + e];
-                    if (a.act == BTS_ACT_ELU) t = act_elu(t);
-                    else if (a.act == BTS_ACT_SIGMOID) t = act_sigmoid(t);
-                    else if (a.act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
-                    v[e] = t * sc;
-                }
-                const size_t o = opix * a.y_stride + co;
-                if (a.vec_store) {
-                    if (a.y_f32) {
-                        float* p = (float*)a.y + o;
-                        f32x4_t t = {v[0], v[1], v[2], v[3]};
-                        if (a.accumulate) { f32x4_t old = *(f32x4_t*)p; t += old; }
-                        *(f32x4_t*)p = t;
-                    } else {
-                        uint16_t* p = (uint16_t*)a.y + o;
-                        if (a.accumulate) {
-                            u32x2_t old = *(u32x2_t*)p;
-                            v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
-                            v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
-                        }
-                        u32x2_t t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                        *(u32x2_t*)p = t;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (co + e >= a.Cout) break;
-                        if (a.y_f32) {
-                            float* p = (float*)a.y + o + e;
-                            *p = a.accumulate ? *p + v[e] : v[e];
-                        } else {
-                            uint16_t* p = (uint16_t*)a.y + o + e;
-                            const float t = a.accumulate ? bf16_bits_to_f32(*p) + v[e] : v[e];
-                            *p = (uint16_t)f32_to_bf16_bits(t);
-                        }
-                    }
-                }
-            }
+            store_block32(a, opix, cb, fk, v);
         }
     }
 }
@@ -259,6 +345,9 @@ int launch_fwd_pp(const ConvK& k, hipStream_t st, int variant);
 // conv_halo_wide.hip: 3x3 radius-1 forward / data-gradient with > 64 output channels on 2-D pixel tiles (patch staged once
 // per channel chunk, weights streamed per tap); BTS_ERR_UNSUPPORTED outside its domain.
 int launch_halo_wide(const ConvK& k, hipStream_t st, int force);
+
+// conv_wgrad_tr.hip: 64 co x 256 column ring form of the transposing weight-gradient kernel (32 < Cout <= 64, bf16)
+int launch_wgrad_ring64(const ConvK& k, hipStream_t st);
 
 // conv_wgrad_tr.hip: bf16 weight gradient of the wide layers (LDS-DMA staging + transpose reads); returns BTS_ERR_UNSUPPORTED
 // when the shape is outside its domain (the caller then falls back to conv_wgrad).

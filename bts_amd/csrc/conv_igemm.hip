@@ -769,51 +769,16 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const size_t opix = ((size_t)n * a.Hy + (oy * a.osc + (g >> 1))) * a.Wy + (ox * a.osc + (g & 1));
+            float v[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int co = co_tile * 32 + 8 * q + 4 * fk;
-                if (co >= a.Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[g][4 * q + e];
-                    if (a.act == BTS_ACT_ELU) t = act_elu(t);
-                    else if (a.act == BTS_ACT_SIGMOID) t = act_sigmoid(t);
-                    else if (a.act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
-                    v[e] = t * sc;
-                }
-                const size_t o = opix * a.y_stride + co;
-                if (a.vec_store) {
-                    if (a.y_f32) {
-                        float* p = (float*)a.y + o;
-                        f32x4_t t = {v[0], v[1], v[2], v[3]};
-                        if (a.accumulate) { f32x4_t old = *(f32x4_t*)p; t += old; }
-                        *(f32x4_t*)p = t;
-                    } else {
-                        uint16_t* p = (uint16_t*)a.y + o;
-                        if (a.accumulate) {
-                            u32x2_t old = *(u32x2_t*)p;
-                            v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
-                            v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
-                        }
-                        u32x2_t t = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                        *(u32x2_t*)p = t;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (co + e >= a.Cout) break;
-                        if (a.y_f32) {
-                            float* p = (float*)a.y + o + e;
-                            *p = a.accumulate ? *p + v[e] : v[e];
-                        } else {
-                            uint16_t* p = (uint16_t*)a.y + o + e;
-                            const float t = a.accumulate ? bf16_bits_to_f32(*p) + v[e] : v[e];
-                            *p = (uint16_t)f32_to_bf16_bits(t);
-                        }
-                    }
-                }
+            for (int r = 0; r < 16; ++r) {
+                float t = acc[g][r];
+                if (a.act == BTS_ACT_ELU) t = act_elu(t);
+                else if (a.act == BTS_ACT_SIGMOID) t = act_sigmoid(t);
+                else if (a.act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
+                v[r] = t * sc;
             }
+            store_block32(a, opix, co_tile * 32, fk, v);
         }
     };
 
@@ -854,9 +819,9 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
             int n2 = 0, y2 = 0, x2 = 0;
             const bool more = tile + 2 < t_end;
             if (more) tile_origin(tile + 2, n2, y2, x2);
-            if (more && !a.accumulate) dma_patch(0, n2, y2, x2, smem + cur * PR_PAD * 128);
+            if (more && !(a.accumulate || a.fold_y)) dma_patch(0, n2, y2, x2, smem + cur * PR_PAD * 128);
             epilogue(acc, n, y0, x0);
-            if (more && a.accumulate) dma_patch(0, n2, y2, x2, smem + cur * PR_PAD * 128);
+            if (more && (a.accumulate || a.fold_y)) dma_patch(0, n2, y2, x2, smem + cur * PR_PAD * 128);   // (the fold reads memory too)
             n = n1; y0 = y1; x0 = x1;
             n1 = n2; y1 = y2; x1 = x2;
         }
@@ -1977,6 +1942,13 @@ static int launch_wgrad(const ConvK& k0, hipStream_t st) {
         BTS_LAUNCH_CHECK();
         return BTS_OK;
     }
+    // 64-output-channel layers (conv2, upconv2, and every other 33..64-channel bf16 layer): 64 x 256 ring form of the transposing
+    // kernel.  Measured against the LDS-halo kernels (gpurun r03k): conv2 481 -> 368 us, upconv2 168 -> 123 us.  BTS_WGRAD_RING64=0: A/B.
+    static const int ring64_on = [] { const char* e = getenv("BTS_WGRAD_RING64"); return e ? atoi(e) : 1; }();
+    if (ring64_on && T::kBytes == 2 && k.Cout > 32 && k.Cout <= 64) {
+        const int rc = launch_wgrad_ring64(k, st);
+        if (rc != BTS_ERR_UNSUPPORTED) return rc;
+    }
     if (T::kBytes == 2 && k.halo_ok && k.nphase == 4 && k.T == 4 && k.Cout <= 64 && wgrad_halo_enabled()) {
         const int ntiles = ceil_div(k.Wg, 32) * ceil_div(k.Hg, 8) * k.N;
         if (ntiles >= 256) {
@@ -2052,6 +2024,17 @@ extern "C" int bts_conv_fwd(const bts_conv_desc_t* d, bts_stream_t stream) {
     k.out_scale_n = d->out_scale_n;
     const int ob = k.y_f32 ? 16 : 8;
     k.vec_store = (d->Cout % 4 == 0) && (d->y_stride % 4 == 0) && (((uintptr_t)d->y & (ob - 1)) == 0);
+    k.fold_y = (const char*)d->fold_elu_y;
+    k.fold_stride = d->fold_elu_stride;
+    // 16-byte stores of bf16 rows (store_block32): BTS_WIDE_STORE=0 keeps the 8-byte form (A/B)
+    static const int wide_on = [] { const char* e = getenv("BTS_WIDE_STORE"); return (e && e[0] == '0') ? 0 : 1; }();
+    k.wide_store = wide_on && !k.y_f32 && k.vec_store && d->y_stride % 8 == 0 && ((uintptr_t)d->y & 15) == 0 &&
+                   (!k.fold_y || (d->fold_elu_stride % 8 == 0 && ((uintptr_t)d->fold_elu_y & 15) == 0));
+    if (k.fold_y) {     // ELU-derivative fold: data-gradient launches only, same layout class as y (the vector form reads it like y)
+        BTS_CHECK_ARG(d->act == BTS_ACT_NONE && d->out_scale == 1.0f && d->out_scale_n == nullptr);
+        BTS_CHECK_ARG(d->fold_elu_stride >= d->Cout);
+        if (k.vec_store) BTS_CHECK_ARG(d->fold_elu_stride % 4 == 0 && ((uintptr_t)d->fold_elu_y & (ob - 1)) == 0);
+    }
     return d->dtype == BTS_F32 ? launch_fwd<F32>(k, (hipStream_t)stream) : launch_fwd<BF16>(k, (hipStream_t)stream);
 }
 

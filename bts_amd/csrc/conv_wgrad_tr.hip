@@ -264,7 +264,7 @@ __global__ __launch_bounds__(WR* WC * 64) void conv_wgrad_ring(const ConvK a) {
     constexpr int GR = NSUB * IPS;           // DMA instructions per thread per chunk
     constexpr int STG = NSUB * SUB;
     constexpr int KS = KC / 16, NM = 4, R = 8;
-    static_assert(KC % RPI == 0 && (NST - 2) * GR <= 63 && NST >= 3, "shape");
+    static_assert(KC % RPI == 0 && (NST - 2) * GR <= 63 && NST >= 2, "shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -443,14 +443,46 @@ __global__ __launch_bounds__(WR* WC * 64) void conv_wgrad_ring(const ConvK a) {
 
 }  // namespace
 
+// 64 co x 256 columns, four waves, two stages (80 KiB: two workgroups per CU): the narrow full-resolution layers (conv2, upconv2:
+// 64 output channels).  Their LDS-halo kernels (conv_wgrad_halo*) transpose through 2-byte LDS scatters and re-stage X per
+// output-channel group (PMC, round 2: 1.1 GB fetched for 0.4 GB); here X is staged once per 256 columns as it lies.
+int launch_wgrad_ring64(const ConvK& k0, hipStream_t st) {
+    ConvK k = k0;
+    if (k.Cout > 64 || k.Cout <= 32) return BTS_ERR_UNSUPPORTED;
+    if ((long)k.N * k.Hy * k.Wy * k.dz_stride * 2 >= (1l << 32) || !segs_fit_u32(k)) return BTS_ERR_UNSUPPORTED;
+    constexpr int NST = 2, LDS = NST * 5 * SUB;
+    k.nchunks = ceil_div(k.M, KC);
+    k.n_co_tiles = 1;
+    k.n_col_tiles = ceil_div((long)k.T * k.Ktot, 256);
+    const int tiles = k.n_col_tiles * k.nphase;
+    const int slots = 2 * bts_cu_count();
+    int splits = slots / tiles;
+    if (splits > k.nchunks / 8) splits = k.nchunks / 8;
+    if (splits < 1) splits = 1;
+    k.chunks_per_split = ceil_div(k.nchunks, splits);
+    splits = ceil_div(k.nchunks, k.chunks_per_split);
+    static DynLdsCache lds_set;
+    if (ensure_dyn_lds((const void*)conv_wgrad_ring<1, 4, NST>, LDS, lds_set) != BTS_OK) return BTS_ERR_LAUNCH;
+    dim3 grid(k.n_col_tiles, splits, k.nphase);
+    hipLaunchKernelGGL((conv_wgrad_ring<1, 4, NST>), grid, dim3(256), (size_t)LDS, st, k);
+    if (hipGetLastError() != hipSuccess) return BTS_ERR_LAUNCH;
+    return BTS_OK;
+}
+
 int launch_wgrad_tr(const ConvK& k0, hipStream_t st) {
     ConvK k = k0;
     if (k.Cout <= 64) return BTS_ERR_UNSUPPORTED;
     if ((long)k.N * k.Hy * k.Wy * k.dz_stride * 2 >= (1l << 32) || !segs_fit_u32(k)) return BTS_ERR_UNSUPPORTED;   // 32-bit byte offsets
     k.nchunks = ceil_div(k.M, KC);
-    // BTS_WGRAD_TR: 1 = the two-stage 128 x 128 kernel of round 2 (A/B); 2 = the 128 x 256 three-stage ring [default]
+    // BTS_WGRAD_TR: 1 = the two-stage 128 x 128 kernel of round 2 everywhere (A/B); 2 = the 128 x 256 three-stage ring where it
+    // pays [default]; 3 = the ring everywhere (A/B)
     static const int mode = [] { const char* e = getenv("BTS_WGRAD_TR"); return e ? atoi(e) : 2; }();
-    if (mode >= 2) {
+    // Measured per layer on one box (gpurun r03c, kernel alone, two-stage 128 x 128 -> ring 128 x 256, TFLOP/s): conv5 771 -> 768,
+    // conv4 726 -> 774, daspp_conv 766 -> 766, conv3 556 -> 589, upconv3 383 -> 478, upconv4 636 -> 633, dilated 3x3 508 -> 496,
+    // ASPP 1x1 380 -> 384, upconv5 665 -> 616: the ring wins where the pixel split is deep (few tiles, long K per workgroup) and
+    // loses where the tiles alone exceed two rounds of the chip (upconv5: 560 ring tiles) -- those keep the 128 x 128 form.
+    const long ring_tiles = (long)ceil_div(k.Cout, 128) * ceil_div((long)k.T * k.Ktot, 256) * k.nphase;
+    if (mode >= 2 && (mode >= 3 || ring_tiles <= 2l * bts_cu_count())) {
         constexpr int NST = 3, LDS = NST * 6 * SUB;
         k.n_co_tiles = ceil_div(k.Cout, 128);
         k.n_col_tiles = ceil_div((long)k.T * k.Ktot, 256);

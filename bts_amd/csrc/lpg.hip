@@ -180,6 +180,37 @@ __global__ __launch_bounds__(256) void lpg_head_bwd_kernel(const float* __restri
     for (int c = 3; c < gpad; ++c) T::st(graw, o + c, 0.f);
 }
 
+
+// ---- plane parameters alone (standalone reduction_1x1.forward, bts.py:112-120): raw -> (sin t cos p, sin t sin p, cos t, dist) -------
+__global__ __launch_bounds__(256) void plane_fwd_kernel(const float* __restrict__ raw, int raw_stride, float* __restrict__ plane,
+                                                        long cells, float max_depth) {
+    const long cell = blockIdx.x * 256l + threadIdx.x;
+    if (cell >= cells) return;
+    const float* rp = raw + (size_t)cell * raw_stride;
+    const Plane p = plane_from_raw(rp[0], rp[1], rp[2], max_depth);
+    *(f32x4_t*)(plane + (size_t)cell * 4) = f32x4_t{p.m1, p.m2, p.m3, p.n4};      // UN-normalised: F.normalize is bts.forward's
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void plane_bwd_kernel(const float* __restrict__ raw, int raw_stride,
+                                                        const float* __restrict__ gplane, void* __restrict__ graw, int gstride,
+                                                        int gpad, long cells, float max_depth) {
+    const long cell = blockIdx.x * 256l + threadIdx.x;
+    if (cell >= cells) return;
+    const float* rp = raw + (size_t)cell * raw_stride;
+    const Plane p = plane_from_raw(rp[0], rp[1], rp[2], max_depth);
+    const f32x4_t g = *(const f32x4_t*)(gplane + (size_t)cell * 4);
+    // m1 = st*cp, m2 = st*sp, m3 = ct, n4 = s2 * max_depth
+    const float gtheta = g.x * p.ct * p.cp + g.y * p.ct * p.sp - g.z * p.st;
+    const float gphi = -g.x * p.st * p.sp + g.y * p.st * p.cp;
+    const float PI = 3.14159274101257324f;
+    const size_t o = (size_t)cell * gstride;
+    T::st(graw, o + 0, gtheta * (PI / 3.0f) * p.s0 * (1.f - p.s0));
+    T::st(graw, o + 1, gphi * (PI * 2.0f) * p.s1 * (1.f - p.s1));
+    T::st(graw, o + 2, g.w * max_depth * p.s2 * (1.f - p.s2));
+    for (int c = 3; c < gpad; ++c) T::st(graw, o + c, 0.f);
+}
+
 // ---- depth-map slot pack / unpack -------------------------------------------------------------
 struct MapsK {
     const float* src[4];
@@ -303,7 +334,23 @@ __global__ __launch_bounds__(256) void silog_bwd_kernel(const float* __restrict_
     // d loss / d d_i = (100 / loss) * (d_i - vf * mean) / count
     const float coef = gloss[0] * (float)(100.0 / ((double)loss[0] * c));
     const float vm = vf * mean;
-    for (long i = blockIdx.x * 256l + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    // 16-byte accesses like the forward pass (est / gt / gest are the [B,1,H,W] maps: 16-byte aligned, n % 4 handled by the tail)
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * 256l + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4_t e = ((const f32x4_t*)est)[i];
+        const f32x4_t g = ((const f32x4_t*)gt)[i];
+        uint32_t mk = 0x01010101u;
+        if (mask) mk = ((const uint32_t*)mask)[i];
+        f32x4_t o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool on = mask ? ((mk >> (8 * k)) & 0xff) != 0 : g[k] > thr;
+            o[k] = on ? coef * ((logf(e[k]) - logf(g[k])) - vm) / e[k] : 0.f;
+        }
+        ((f32x4_t*)gest)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {   // tail
+        const long i = (n4 << 2) + threadIdx.x;
         const float e = est[i], g = gt[i];
         const bool on = mask ? mask[i] != 0 : g > thr;
         gest[i] = on ? coef * ((logf(e) - logf(g)) - vm) / e : 0.f;
@@ -399,6 +446,29 @@ extern "C" int bts_lpg_head_bwd(const float* raw, int raw_stride, const float* g
     return BTS_OK;
 }
 
+extern "C" int bts_plane_fwd(const float* raw, int raw_stride, float* plane, long cells, float max_depth, bts_stream_t stream) {
+    BTS_CHECK_ARG(raw && plane && cells > 0 && raw_stride >= 3 && max_depth > 0.f && ((uintptr_t)plane & 15) == 0);
+    hipLaunchKernelGGL(plane_fwd_kernel, dim3(ceil_div(cells, 256)), dim3(256), 0, (hipStream_t)stream, raw, raw_stride, plane, cells,
+                       max_depth);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_plane_bwd(const float* raw, int raw_stride, const float* grad_plane, void* grad_raw, int grad_dtype,
+                             int grad_stride, int grad_pad, long cells, float max_depth, bts_stream_t stream) {
+    BTS_CHECK_ARG(raw && grad_plane && grad_raw && cells > 0 && raw_stride >= 3 && max_depth > 0.f);
+    BTS_CHECK_ARG((grad_dtype == BTS_F32 || grad_dtype == BTS_BF16) && grad_pad >= 3 && grad_stride >= grad_pad);
+    BTS_CHECK_ARG(((uintptr_t)grad_plane & 15) == 0);
+    dim3 g(ceil_div(cells, 256)), b(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (grad_dtype == BTS_F32)
+        hipLaunchKernelGGL(plane_bwd_kernel<F32>, g, b, 0, st, raw, raw_stride, grad_plane, grad_raw, grad_stride, grad_pad, cells, max_depth);
+    else
+        hipLaunchKernelGGL(plane_bwd_kernel<BF16>, g, b, 0, st, raw, raw_stride, grad_plane, grad_raw, grad_stride, grad_pad, cells, max_depth);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
 extern "C" int bts_pack_maps(const float* const* src, const int* ds, int n_src, void* dst, int dst_dtype, int dst_stride,
                              int C, int N, int H, int W, bts_stream_t stream) {
     BTS_CHECK_ARG(src && ds && dst && n_src >= 1 && n_src <= 4 && N > 0 && H > 0 && W > 0);
@@ -456,7 +526,10 @@ extern "C" int bts_silog_bwd(const float* est, const float* gt, const uint8_t* m
                              const double* stats, const float* loss, const float* grad_loss, float* grad_est,
                              bts_stream_t stream) {
     BTS_CHECK_ARG(est && gt && stats && loss && grad_loss && grad_est && n > 0);
-    const int nb = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    BTS_CHECK_ARG(((uintptr_t)est & 15) == 0 && ((uintptr_t)gt & 15) == 0 && ((uintptr_t)grad_est & 15) == 0);
+    BTS_CHECK_ARG(mask == nullptr || ((uintptr_t)mask & 3) == 0);
+    const long nv = (n + 3) / 4;
+    const int nb = (int)((nv + 255) / 256 > 4096 ? 4096 : (nv + 255) / 256);
     hipLaunchKernelGGL(silog_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, est, gt, mask, thr, n, vf, stats, loss,
                        grad_loss, grad_est);
     BTS_LAUNCH_CHECK();

@@ -305,6 +305,7 @@ struct ChainBwdK {
     const float* gout;  // grad of depth [B][h*k][w*k] (k > 1) or of the sigmoid map [cells] (k = 1)
     void* dx;
     int dx_stride, dx_accumulate;
+    int fold_elu;       // x is an ELU output and this launch completes its gradient: store (dx [+ old]) * ELU'(x)
     float* dw[6];       // per layer: packed f32 weight gradient [Cout][ld], accumulated atomically
     int dw_ld[6];
     long cells;
@@ -542,9 +543,16 @@ __global__ __launch_bounds__(256, (C0 >= 128 ? 1 : 2)) void lpg_chain_bwd_kernel
                     if (ch < C0) {
                         float v0 = dA[tn][4 * q], v1 = dA[tn][4 * q + 1], v2 = dA[tn][4 * q + 2], v3 = dA[tn][4 * q + 3];
                         uint2* dst = (uint2*)(px + ch * 2);
+                        uint2 xv = make_uint2(0u, 0u);
+                        if (a.fold_elu)       // the tile's input was fetched one iteration ago: an L2 hit (its register image is in
+                            xv = *(const uint2*)((const char*)a.x + ((size_t)t.cell * a.x_stride + ch) * 2);   // fragment order)
                         if (a.dx_accumulate) {
                             const uint2 o = *dst;
                             v0 += bf16_lo(o.x); v1 += bf16_hi(o.x); v2 += bf16_lo(o.y); v3 += bf16_hi(o.y);
+                        }
+                        if (a.fold_elu) {
+                            v0 *= elu_grad_from_out(bf16_lo(xv.x)); v1 *= elu_grad_from_out(bf16_hi(xv.x));
+                            v2 *= elu_grad_from_out(bf16_lo(xv.y)); v3 *= elu_grad_from_out(bf16_hi(xv.y));
                         }
                         *dst = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                     }
@@ -594,8 +602,8 @@ extern "C" int bts_lpg_chain_fwd(const void* x, int dtype, int x_stride, int c0,
 
 extern "C" int bts_lpg_chain_bwd(const void* x, int dtype, int x_stride, int c0, const void* w_frags, int w_bytes,
                                  const void* wt_frags, int wt_bytes, const float* grad_out, void* grad_x, int grad_x_stride,
-                                 int accumulate, float* const* grad_w, const int* grad_w_ld, int n_layers, long cells,
-                                 int in_h, int in_w, int upratio, float max_depth, bts_stream_t stream) {
+                                 int accumulate, int x_is_elu_output, float* const* grad_w, const int* grad_w_ld, int n_layers,
+                                 long cells, int in_h, int in_w, int upratio, float max_depth, bts_stream_t stream) {
     BTS_CHECK_ARG(x && w_frags && wt_frags && grad_out && grad_x && grad_w && grad_w_ld && cells > 0 && in_h > 0 && in_w > 0);
     BTS_CHECK_ARG(w_bytes > 0 && w_bytes % 1024 == 0 && wt_bytes > 0 && wt_bytes % 1024 == 0);
     BTS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_frags & 15) == 0 && ((uintptr_t)wt_frags & 15) == 0);
@@ -611,6 +619,7 @@ extern "C" int bts_lpg_chain_bwd(const void* x, int dtype, int x_stride, int c0,
     k.wf = (const char*)w_frags; k.wf_bytes = w_bytes;
     k.wt = (const char*)wt_frags; k.wt_bytes = wt_bytes;
     k.gout = grad_out; k.dx = grad_x; k.dx_stride = grad_x_stride; k.dx_accumulate = accumulate;
+    k.fold_elu = x_is_elu_output;
     for (int l = 0; l < n_layers; ++l) {
         BTS_CHECK_ARG(grad_w[l] && grad_w_ld[l] > 0);
         k.dw[l] = grad_w[l]; k.dw_ld[l] = grad_w_ld[l];

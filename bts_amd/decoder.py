@@ -27,6 +27,11 @@ KITTI_FOCAL_REF = 715.0873  # bts.py:264
 BN_MOMENTUM = 0.01          # bts.py:154 etc.
 # fused recompute backward of the narrow LPG chains (A/B switch for measurements: BTS_CHAIN_BWD=0 trains them layer-wise)
 FUSED_CHAIN_BWD = os.environ.get("BTS_CHAIN_BWD", "1") != "0"
+# ELU derivative folded into the launch that completes the gradient of a conv+ELU output (A/B switch: BTS_FOLD_ELU=0 runs the
+# separate act_bwd pass per convolution, as round 2 did)
+FOLD_ELU = os.environ.get("BTS_FOLD_ELU", "1") != "0"
+# get_depth on the streaming one-output-channel kernels (csrc/conv_c1.hip); BTS_CONV_C1=0: the MFMA kernels (A/B)
+USE_CONV_C1 = os.environ.get("BTS_CONV_C1", "1") != "0"
 
 
 def reduction_specs(c_in, c_out, is_final):
@@ -43,11 +48,13 @@ def reduction_specs(c_in, c_out, is_final):
 
 class Act:
     """An activation (NHWC tensor, or a single-channel f32 map [N,H,W]) and its gradient buffer."""
-    __slots__ = ("t", "g", "stats", "g_is_dz")
+    __slots__ = ("t", "g", "stats", "g_is_dz", "act", "uses")
 
-    def __init__(self, t):
+    def __init__(self, t, act=ACT_NONE):
         self.t, self.g, self.stats = t, None, None
-        self.g_is_dz = False      # set by a BatchNorm backward that folded this tensor's ELU derivative into what it wrote to g
+        self.act = act            # activation the producing convolution applied (ACT_ELU: candidates for the derivative fold)
+        self.uses = 0             # consumers registered so far (forward order): the FIRST one is the LAST writer of g in backward
+        self.g_is_dz = False      # set by the backward op that completed g AND folded this tensor's ELU derivative into it
 
 
 class DecoderPlan:
@@ -146,6 +153,7 @@ class PackSet:
         self.fblocks = self._assign(fjobs, lambda j: _cdiv(j.R if j.mode == 0 else j.K, 32) * _cdiv(j.K if j.mode == 0 else j.R, 32))
         self.dblocks = self._assign(djobs, lambda j: _cdiv(j.R if j.mode == 0 else j.K, 32) * _cdiv(j.K if j.mode == 0 else j.R, 32))
         self.ublocks = self._assign(ujobs, lambda j: _cdiv(j.Cout * j.Cin, 256))
+        self.prepacked = None      # (event, dgrad_too) of a side-stream repack issued by prepack(): consumed by the next pass
         self.fjobs, self.nf = self._upload(fjobs, dev), len(fjobs)
         self.djobs, self.nd = self._upload(djobs, dev), len(djobs)
         self.ujobs, self.nu = self._upload(ujobs, dev), len(ujobs)
@@ -184,6 +192,20 @@ class PackSet:
         _lib.call("bts_pack_weight_batch", C.c_void_p(self.djobs.data_ptr()), self.nd, self.dblocks, _lib.dtype_code(self.dtype),
                   _lib.stream_ptr())
 
+    def prepack(self, side, with_dgrad):
+        """Repack on stream `side` behind everything already queued on the current stream (the optimizer's update of the weights);
+        the next DecoderRun waits for the recorded event instead of packing in line.  BtsModel.forward calls this BEFORE the
+        encoder, so the two launches (110 us each at DenseNet161 width: 82 MB of f32 weights in, 41 MB of bf16 operands out)
+        run under the encoder's kernels instead of in front of the decoder's."""
+        side.wait_stream(torch.cuda.current_stream(side.device))
+        with torch.cuda.stream(side):
+            self.pack_forward()
+            if with_dgrad:
+                self.pack_dgrad()
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self.prepacked = (ev, bool(with_dgrad))
+
     def unpack_all(self, dwp_arena, gw_arena):
         if profiler.ACTIVE is not None:
             profiler.note("unpack_wgrad_batch", "hbm", (self.dwp_total + self.gw_total) * 4)
@@ -209,9 +231,19 @@ class DecoderRun:
             ps = PackSet(plan, P, dtype)
             plan.pack_cache[(dtype, dev)] = ps
         self.packs = ps
+        self.dgrad_packed = False
         self.dwp_arena = None
 
     # ---- ops -------------------------------------------------------------------------------
+    def _use(self, a, can_fold):
+        """Register a consumer of activation `a` (call once per consumer, in forward order).  Returns True when this consumer
+        should fold a's ELU derivative into the gradient it writes: it is a's FIRST consumer -- the tape runs backwards, so its
+        backward is the LAST writer of a.g, i.e. the one that completes it -- a is a conv+ELU output, and the consumer's kernel
+        has the fold (convolution data-gradients, the fused chain backward, the BatchNorm backward)."""
+        first = a.uses == 0
+        a.uses += 1
+        return bool(self.record and FOLD_ELU and first and can_fold and a.act == ACT_ELU and a.t.dim() == 4)
+
     def feature(self, f, relu=False):
         """Encoder feature (NCHW, f32 or bf16 under autocast) -> NHWC activation; no intermediate casts."""
         src = f.detach()
@@ -238,7 +270,8 @@ class DecoderRun:
             cp = pad_to(L.cout, vec_of(odt))
             out = (torch.zeros if cp != L.cout else torch.empty)((N, Ho, Wo, cp), dtype=odt, device=dev)
         L.forward(x, wp, out, act, out_scale, out_scale_n)
-        y = Act(out)
+        y = Act(out, act if (not out_map and not out_f32 and out_scale == 1.0 and out_scale_n is None) else ACT_NONE)
+        folds = [self._use(s, s.t.dtype == self.dtype) for s in segs]
         if self.record:
             def bwd():
                 if y.g is None:
@@ -254,10 +287,39 @@ class DecoderRun:
                     acc = s.g is not None
                     if not acc:
                         s.g = torch.empty(s.t.shape, dtype=self.dtype, device=dev)
-                    L.dgrad(dz, self.packs.dgrad[(name, i)], i, s.g, acc)
+                    L.dgrad(dz, self.packs.dgrad[(name, i)], i, s.g, acc, s.t if folds[i] else None)
+                    if folds[i]:
+                        s.g_is_dz = True
                 off, shape = self.packs.dwp_off[name]
                 n_el = shape[0] * shape[1] * shape[2]
                 L.wgrad_packed(x, dz, self.dwp_arena[off:off + n_el].view(shape))
+            self.tape.append(bwd)
+        return y
+
+    def conv_c1(self, name, x, out_scale, out_scale_n):
+        """3x3 convolution to one channel + sigmoid * scale (get_depth, bts.py:193-194, 262-264) on the streaming kernels of
+        csrc/conv_c1.hip: forward and data gradient; the weight gradient stays with conv_wgrad_c1.  Falls back to the generic
+        convolution outside their domain."""
+        L = self.plan.layers[name]
+        if not (USE_CONV_C1 and L.cout == 1 and L.kk == 9 and L.dil == 1 and not L.up and ops.conv_c1_supported(x.t)):
+            return self.conv(name, [x], ACT_SIGMOID, out_map=True, out_scale=out_scale, out_scale_n=out_scale_n)
+        w = self.P[name + ".weight"]
+        y = Act(ops.conv3x3_c1_fwd(x.t, w, out_scale, out_scale_n))
+        fold = self._use(x, True)
+        if self.record:
+            def bwd():
+                if y.g is None:
+                    return
+                acc = x.g is not None
+                if not acc:
+                    x.g = torch.empty(x.t.shape, dtype=self.dtype, device=x.t.device)
+                ops.conv3x3_c1_dgrad(y.g, y.t, w, x.g, acc, out_scale, out_scale_n, x.t if fold else None)
+                if fold:
+                    x.g_is_dz = True
+                dz = ops.act_bwd(y.g, y.t, ACT_SIGMOID, out_dtype=self.dtype, out_channels=self.v, y_scale=out_scale,
+                                 y_scale_n=out_scale_n)
+                off, shape = self.packs.dwp_off[name]
+                L.wgrad_packed([x.t], dz, self.dwp_arena[off:off + shape[0] * shape[1] * shape[2]].view(shape))
             self.tape.append(bwd)
         return y
 
@@ -301,8 +363,9 @@ class DecoderRun:
                 nbt.add_(1)
         y = Act(out)
         y2 = Act(out2) if relu_copy else None
-        fold = x_act == ACT_ELU and len(segs) == 1
-        if x_act != ACT_NONE and not fold:
+        firsts = [self._use(sg, True) for sg in segs]
+        fold = x_act == ACT_ELU and len(segs) == 1 and (firsts[0] or not FOLD_ELU)
+        if x_act != ACT_NONE and len(segs) != 1:
             raise BtsAmdError("bn_cat: x_act is only supported for a single ELU input")
         if self.record:
             def bwd():
@@ -333,6 +396,7 @@ class DecoderRun:
         return (y, y2) if relu_copy else y
 
     def relu(self, x):
+        self._use(x, False)
         y = Act(ops.affine_act(x.t, None, None, ACT_RELU))
         if self.record:
             def bwd():
@@ -346,6 +410,7 @@ class DecoderRun:
         return y
 
     def head(self, raw, k):
+        self._use(raw, False)
         d = Act(ops.lpg_head_fwd(raw.t, k, self.max_depth))
         if self.record:
             def bwd():
@@ -355,7 +420,22 @@ class DecoderRun:
             self.tape.append(bwd)
         return d
 
+    def plane(self, raw):
+        """(theta, phi, dist) -> un-normalised plane parameters (bts.py:112-120) as its own op: the standalone reduction_1x1
+        module's tail; inside the decoder this arithmetic is part of the fused head kernels."""
+        self._use(raw, False)
+        y = Act(ops.plane_fwd(raw.t, self.max_depth))
+        if self.record:
+            def bwd():
+                if y.g is None:
+                    return
+                raw.g = ops.plane_bwd(raw.t, y.g, self.max_depth, self.dtype, self.v)
+            self.tape.append(bwd)
+        return y
+
     def slots(self, maps, ds, N, H, W):
+        for m in maps:
+            self._use(m, False)
         y = Act(ops.pack_maps([m.t for m in maps], ds, N, H, W, self.dtype))
         if self.record:
             def bwd():
@@ -409,6 +489,7 @@ class DecoderRun:
         if x.t.shape[3] != c0:
             raise BtsAmdError("reduction chain %s: unexpected channel padding" % name)
         frags, frags_t = self._chain_pack(name, start, ws, train)
+        fold = self._use(x, train)              # the recompute backward re-reads x anyway: folding x's ELU derivative is free
         d = Act(chain_mod.chain_fwd(x.t, frags, c0, same, k, self.max_depth))
         if train:
             def bwd():
@@ -421,7 +502,9 @@ class DecoderRun:
                 for key in keys:
                     off, shape = self.packs.dwp_off[key]
                     gws.append(self.dwp_arena[off:off + shape[0] * shape[1] * shape[2]].view(shape[0], shape[1] * shape[2]))
-                chain_mod.chain_bwd(x.t, frags, frags_t, c0, k, self.max_depth, d.g, x.g, acc, gws)
+                chain_mod.chain_bwd(x.t, frags, frags_t, c0, k, self.max_depth, d.g, x.g, acc, gws, fold)
+                if fold:
+                    x.g_is_dz = True
             self.tape.append(bwd)
         return d
 
@@ -451,7 +534,12 @@ class DecoderRun:
     # ---- schedule (bts.forward, bts.py:196-266) ------------------------------------------------
     def forward(self, features, focal):
         f = features
-        self.packs.pack_forward()
+        if self.packs.prepacked is not None:              # side-stream repack issued before the encoder (BtsModel.forward)
+            ev, self.dgrad_packed = self.packs.prepacked
+            self.packs.prepacked = None
+            torch.cuda.current_stream(f[0].device).wait_event(ev)
+        else:
+            self.packs.pack_forward()
         N, _, H2, W2 = f[0].shape
         H, W = 2 * H2, 2 * W2
         s0, s1, s2, s3 = (self.feature(f[i]) for i in range(4))
@@ -482,7 +570,7 @@ class DecoderRun:
         scale_n = None
         if self.dataset == "kitti":                                         # :263-264
             scale_n = (focal.detach().to(device=i1.t.device, dtype=torch.float32) / KITTI_FOCAL_REF).contiguous()
-        depth = self.conv("get_depth.0", [i1], ACT_SIGMOID, out_map=True, out_scale=self.max_depth, out_scale_n=scale_n)
+        depth = self.conv_c1("get_depth.0", i1, self.max_depth, scale_n)
         self.outs = [d8, d4, d2, r1, depth]
         return tuple(o.t.view(N, 1, H, W) for o in self.outs)
 
@@ -494,7 +582,8 @@ class DecoderRun:
                 # the LPG maps also receive gradient through conv1/conv3/conv2: own the buffer
                 o.g = g.reshape(o.t.shape).to(torch.float32).clone(memory_format=torch.contiguous_format)
         dev = next(iter(self.packs.fwd.values())).device
-        self.packs.pack_dgrad()
+        if not self.dgrad_packed:
+            self.packs.pack_dgrad()
         self.dwp_arena = torch.zeros(self.packs.dwp_total, dtype=torch.float32, device=dev)     # one memset for every layer
         for fn in reversed(self.tape):
             fn()

@@ -16,11 +16,11 @@ device raises.
 """
 
 import operator
+import os
 
 import torch
 import torch.nn as nn
 
-import math
 
 from . import ops
 from ._lib import ACT_ELU, ACT_NONE, BtsAmdError, require_gpu
@@ -224,25 +224,15 @@ class reduction_1x1(nn.Sequential):
             keys.append(key)
         self._chain = "reduc1x1" if is_final else "reduc"           # DecoderRun.chain ends with the sigmoid map for reduc1x1
         self._plan = _BlockPlan(layers, {self._chain: keys})
-        self._cout = 1 if is_final else 3
+        self._cout = 1 if is_final else 4
         self.compute_dtype = torch.float32
 
     def _schedule(self, run, a):
-        return run.chain(self._chain, a)
+        raw = run.chain(self._chain, a)                              # 1x1 + ELU chain on the HIP kernels (bts.py:110)
+        return raw if self.is_final else run.plane(raw)              # sigmoid map (bts.py:93-96) / plane parameters (:112-120)
 
     def forward(self, net):
-        raw = _run_block(self, net)                                  # 1x1 + ELU chain on the HIP kernels (bts.py:110)
-        if self.is_final:
-            return raw                                               # sigmoid map (bts.py:93-96)
-        # plane parameters -> (n1, n2, n3, n4), bts.py:112-120: a dozen elementwise ops on a [B,3,h,w] tensor; inside the
-        # decoder this tail lives in the fused LPG head kernels, the standalone module keeps it as (differentiable) torch ops
-        theta = torch.sigmoid(raw[:, 0]) * math.pi / 3
-        phi = torch.sigmoid(raw[:, 1]) * math.pi * 2
-        dist = torch.sigmoid(raw[:, 2]) * self.max_depth
-        n1 = torch.mul(torch.sin(theta), torch.cos(phi)).unsqueeze(1)
-        n2 = torch.mul(torch.sin(theta), torch.sin(phi)).unsqueeze(1)
-        n3 = torch.cos(theta).unsqueeze(1)
-        return torch.cat([n1, n2, n3, dist.unsqueeze(1)], dim=1)
+        return _run_block(self, net)                                 # [B,1,h,w] sigmoid map, or [B,4,h,w] (n1, n2, n3, dist)
 
 
 class _LpgFn(torch.autograd.Function):
@@ -349,11 +339,36 @@ class bts(nn.Module):
         self._plan = DecoderPlan(f, nf)
         self._param_names = tuple(n for n, _ in self.named_parameters())
         self._param_getters = tuple(operator.attrgetter(n) for n in self._param_names)
+        self._pack_streams = {}        # device -> side stream of prepack()
         # activation dtype of the decoder kernels: f32 (parity) or bf16 (throughput); not a parameter
         self.compute_dtype = getattr(params, "decoder_dtype", torch.float32)
         if isinstance(self.compute_dtype, str):
             self.compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32,
                                   "float32": torch.float32}[self.compute_dtype]
+
+    def prepack(self):
+        """Start this step's weight repacking on a side stream (overlaps whatever the caller runs next: the encoder)."""
+        names = self._param_names
+        params = tuple(g(self) for g in self._param_getters)
+        # Off by default: measured (gpurun r03j, whole step replayed from one hipGraph) 60.2 ms with the fork against 58.6 ms
+        # without -- the two 110-us launches do disappear from the decoder's critical path, but a captured graph with a second
+        # branch replays slower on this ROCm than a single-stream one, and the encoder is not short of work to overlap with.
+        # BTS_PREPACK=1 turns it on (eager multi-stream runs).
+        if not params or not params[0].is_cuda or os.environ.get("BTS_PREPACK", "0") != "1":
+            return
+        from .decoder import PackSet
+        P = dict(zip(names, (p.detach() for p in params)))
+        dt, dev = self.compute_dtype, params[0].device
+        layer_names = list(self._plan.layers)
+        key = (dt, tuple(P[n + ".weight"].data_ptr() for n in layer_names))
+        ps = self._plan.pack_cache.get((dt, dev))
+        if ps is None or ps.key != key:
+            ps = PackSet(self._plan, P, dt)
+            self._plan.pack_cache[(dt, dev)] = ps
+        side = self._pack_streams.get(dev)
+        if side is None:
+            side = self._pack_streams[dev] = torch.cuda.Stream(device=dev)
+        ps.prepack(side, torch.is_grad_enabled() and any(p.requires_grad for p in params))
 
     def forward(self, features, focal):
         feats = list(features[:5])
@@ -431,5 +446,6 @@ class BtsModel(nn.Module):
         self.decoder = bts(params, self.encoder.feat_out_channels, params.bts_size)
 
     def forward(self, x, focal):
+        self.decoder.prepack()                   # optional (BTS_PREPACK=1): weight repack on a side stream under the encoder
         skip_feat = self.encoder(x)
         return self.decoder(skip_feat, focal)

@@ -83,6 +83,28 @@ def lpg_head_bwd(raw, grad_depth, k, max_depth, grad_dtype, grad_pad):
     return g
 
 
+def plane_fwd(raw, max_depth):
+    """raw [B,h,w,>=3] f32 -> un-normalised plane parameters [B,h,w,4] f32 (bts.py:112-120)."""
+    _lib.require_gpu(raw)
+    B, h, w, _ = raw.shape
+    assert raw.dtype == torch.float32
+    plane = torch.empty((B, h, w, 4), dtype=torch.float32, device=raw.device)
+    if profiler.ACTIVE is not None:
+        profiler.note("plane_fwd", "hbm", B * h * w * 32)
+    call("bts_plane_fwd", _p(raw), pix_stride(raw), _p(plane), B * h * w, float(max_depth), stream_ptr())
+    return plane
+
+
+def plane_bwd(raw, grad_plane, max_depth, grad_dtype, grad_pad):
+    B, h, w, _ = raw.shape
+    g = torch.empty((B, h, w, grad_pad), dtype=grad_dtype, device=raw.device)
+    if profiler.ACTIVE is not None:
+        profiler.note("plane_bwd", "hbm", B * h * w * (32 + grad_pad * g.element_size()))
+    call("bts_plane_bwd", _p(raw), pix_stride(raw), _p(grad_plane.contiguous()), _p(g), dtype_code(grad_dtype), grad_pad, grad_pad,
+         B * h * w, float(max_depth), stream_ptr())
+    return g
+
+
 def pack_maps(maps, ds, N, H, W, dtype):
     """maps: list (<=4) of f32 [N, H*ds, W*ds] tensors -> NHWC [N,H,W,VEC] slot buffer."""
     Cp = vec_of(dtype)
@@ -105,6 +127,39 @@ def unpack_maps(gdst, gmaps, ds):
     if profiler.ACTIVE is not None:
         profiler.note("unpack_maps", "hbm", N * H * W * (8 * n + gdst.shape[3] * gdst.element_size()))
     call("bts_unpack_maps", _p(gdst), dtype_code(gdst.dtype), pix_stride(gdst), dst, dsa, n, N, H, W, stream_ptr())
+
+
+# ---------------------------------------------------------------------------------------------
+# get_depth: 3x3 convolution to one channel + sigmoid * scale (csrc/conv_c1.hip)
+# ---------------------------------------------------------------------------------------------
+def conv_c1_supported(x):
+    return x.dim() == 4 and x.shape[3] <= 64 and (x.shape[3] // vec_of(x.dtype)) in (2, 4, 8, 16) \
+        and x.shape[3] % vec_of(x.dtype) == 0
+
+
+def conv3x3_c1_fwd(x, w, out_scale, out_scale_n=None):
+    """x NHWC [N,H,W,C]; w f32 [1,C,3,3] (PyTorch layout) -> f32 map [N,H,W] = sigmoid(conv3x3) * out_scale * out_scale_n[n]."""
+    _lib.require_gpu(x)
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, H, W), dtype=torch.float32, device=x.device)
+    if profiler.ACTIVE is not None:
+        profiler.note("conv_c1_fwd", "hbm", N * H * W * (Cc * x.element_size() + 4), "get_depth.fwd")
+    call("bts_conv3x3_c1_fwd", _p(x), dtype_code(x.dtype), pix_stride(x), Cc, _p(w), _p(y), N, H, W, float(out_scale),
+         _p(out_scale_n), stream_ptr())
+    return y
+
+
+def conv3x3_c1_dgrad(grad_y, y, w, gx, accumulate, out_scale, out_scale_n=None, fold_elu_y=None):
+    """gx (+)= data gradient of conv3x3_c1_fwd (sigmoid derivative included), optionally through the ELU of fold_elu_y."""
+    N, H, W, Cc = gx.shape
+    if profiler.ACTIVE is not None:
+        es = gx.element_size()
+        profiler.note("conv_c1_dgrad", "hbm", N * H * W * (8 + Cc * es * (1 + int(bool(accumulate)) + int(fold_elu_y is not None))),
+                      "get_depth.dgrad")
+    call("bts_conv3x3_c1_dgrad", _p(grad_y), _p(y), _p(w), _p(gx), dtype_code(gx.dtype), pix_stride(gx), Cc, int(bool(accumulate)),
+         _p(fold_elu_y), pix_stride(fold_elu_y) if fold_elu_y is not None else 0, N, H, W, float(out_scale), _p(out_scale_n),
+         stream_ptr())
+    return gx
 
 
 # ---------------------------------------------------------------------------------------------

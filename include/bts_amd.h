@@ -88,6 +88,14 @@ int bts_lpg_head_bwd(const float* raw, int raw_stride, const float* grad_depth,
                      void* grad_raw, int grad_dtype, int grad_stride, int grad_pad,
                      int batch, int in_h, int in_w, int upratio, float max_depth, bts_stream_t stream);
 
+/* The plane-parameter tail of reduction_1x1.forward on its own (bts.py:112-120; the standalone module's forward -- inside the
+ * decoder it lives in the fused head kernels): plane[cell] = (sin t cos p, sin t sin p, cos t, sigmoid(r2) * max_depth), NOT
+ * normalised (F.normalize is bts.forward's, bts.py:223-226); f32 [cells][4].  Backward: grad_plane [cells][4] f32 -> grad_raw as
+ * in bts_lpg_head_bwd. */
+int bts_plane_fwd(const float* raw, int raw_stride, float* plane, long cells, float max_depth, bts_stream_t stream);
+int bts_plane_bwd(const float* raw, int raw_stride, const float* grad_plane, void* grad_raw, int grad_dtype,
+                  int grad_stride, int grad_pad, long cells, float max_depth, bts_stream_t stream);
+
 /* Fused LPG head, forward (no-grad passes; in training together with bts_lpg_chain_bwd below, which recomputes it):
  * the whole reduction_1x1 chain (1x1 conv + ELU, halving the channels down to 8,
  * bts.py:83-108) + plane parameters + normalisation + LPG + /max_depth in ONE pass over the dense feature map
@@ -109,10 +117,11 @@ int bts_lpg_chain_fwd(const void* x, int dtype, int x_stride, int c0, int same_f
  *   grad_out   f32: [B][h*k][w*k] gradient of the depth map (k = 8/4/2) or [cells] of the sigmoid map (k = 1)
  *   grad_x     [cells][grad_x_stride] in `dtype`; accumulate != 0 adds to its contents
  *   grad_w     n_layers pointers: f32 [Cout_l][grad_w_ld[l]], accumulated with atomics (caller zeroes)
- * Returns BTS_ERR_UNSUPPORTED for f32 or chain shapes without an instantiation (caller runs the layer-wise path). */
+ * Returns BTS_ERR_UNSUPPORTED for f32 or chain shapes without an instantiation (caller runs the layer-wise path).  * x_is_elu_output: x is the ELU output of the producing convolution and this call COMPLETES its gradient (it is the last
+ * writer): the value stored is (dx [+ old]) * ELU'(x), so that convolution's backward needs no activation-derivative pass. */
 int bts_lpg_chain_bwd(const void* x, int dtype, int x_stride, int c0, const void* w_frags, int w_bytes,
                       const void* wt_frags, int wt_bytes, const float* grad_out, void* grad_x, int grad_x_stride,
-                      int accumulate, float* const* grad_w, const int* grad_w_ld, int n_layers, long cells,
+                      int accumulate, int x_is_elu_output, float* const* grad_w, const int* grad_w_ld, int n_layers, long cells,
                       int in_h, int in_w, int upratio, float max_depth, bts_stream_t stream);
 
 /* Gather up to 4 single-channel f32 maps into channels 0..n-1 of an NHWC buffer (the depth-map
@@ -183,9 +192,30 @@ typedef struct {
     float out_scale;        /* multiplies act(acc) */
     const float* out_scale_n; /* optional [N] per-image multiplier (kitti focal scaling, bts.py:263-264) */
     int32_t accumulate;     /* 1: y += result (gradient accumulation); requires act == NONE */
+    /* Data-gradient launches only (act == NONE): when fold_elu_y != NULL the value finally stored is
+     *     (result [+ old y]) * ELU'(fold_elu_y[pixel][co]),   ELU' = (v > 0 ? 1 : v + 1)  from the ELU OUTPUT v,
+     * i.e. the launch that completes the gradient w.r.t. an ELU output also takes it through the ELU (bts.py:74-79, 156-161 etc.),
+     * and the producing convolution's backward needs no separate activation-derivative pass.  Same geometry and dtype as y,
+     * pixel stride fold_elu_stride. */
+    const void* fold_elu_y;
+    int32_t fold_elu_stride;
 } bts_conv_desc_t;
 
 int bts_conv_fwd(const bts_conv_desc_t* d, bts_stream_t stream);
+
+/* 3x3 convolution (padding 1) to ONE output channel + sigmoid * scale, the `get_depth` layer (bts.py:193-194, 262-264), as a
+ * streaming kernel (csrc/conv_c1.hip) instead of a 1-of-32-rows MFMA tile:
+ *     y[n][p] = sigmoid(sum_{t,c} x[n][p + t][c] * w[0][c][t]) * out_scale * (out_scale_n ? out_scale_n[n] : 1)
+ * x: NHWC (dtype, x_stride), C <= 128 B of channels per pixel; w: the PyTorch-layout f32 weight [1][C][3][3] (rounded to bf16 in
+ * the kernel when dtype is bf16, as bts_pack_weight does); y: f32 [N][H][W].  BTS_ERR_UNSUPPORTED outside that domain (use
+ * bts_conv_fwd).
+ * Data gradient: dz = grad_y * sc * s * (1 - s) with s = y / sc (the sigmoid through its output), then
+ *     grad_x[n][p][c] (+)= sum_t dz[n][p - t] * w[0][c][t],   optionally * ELU'(fold_elu_y[n][p][c]) as in bts_conv_desc_t. */
+int bts_conv3x3_c1_fwd(const void* x, int dtype, int x_stride, int C, const float* w, float* y, int N, int H, int W,
+                       float out_scale, const float* out_scale_n, bts_stream_t stream);
+int bts_conv3x3_c1_dgrad(const float* grad_y, const float* y, const float* w, void* grad_x, int dtype, int grad_x_stride,
+                         int C, int accumulate, const void* fold_elu_y, int fold_elu_stride, int N, int H, int W,
+                         float out_scale, const float* out_scale_n, bts_stream_t stream);
 
 /* Weight gradient of the convolution described by `d` (d->w, d->y unused):
  *   dw[co][p*T+t][k] += sum_pixels dz[out pixel][co] * x_t[in pixel][k]

@@ -92,12 +92,15 @@ def test_header_is_plain_c99_and_struct_layouts_match(tmp_path):
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bts_amd.h"\n'
                    'int main(void) {\n'
-                   '  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(bts_conv_desc_t), sizeof(bts_pack_job_t), sizeof(bts_unpack_job_t),\n'
+                   '  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(bts_conv_desc_t), sizeof(bts_pack_job_t), sizeof(bts_unpack_job_t),\n'
                    '         sizeof(bts_aug_t), offsetof(bts_pack_job_t, first_block), offsetof(bts_unpack_job_t, first_block),\n'
-                   '         offsetof(bts_aug_t, color));\n  return 0;\n}\n')
+                   '         offsetof(bts_aug_t, color), sizeof(bts_bn_desc_t), sizeof(bts_bn_seg_t), offsetof(bts_bn_desc_t, gamma),\n'
+                   '         offsetof(bts_bn_desc_t, y2), offsetof(bts_conv_desc_t, fold_elu_y));\n  return 0;\n}\n')
     exe = tmp_path / "layout"
     subprocess.check_call([cc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(_lib.ConvDesc), ctypes.sizeof(_lib.PackJob), ctypes.sizeof(_lib.UnpackJob), ctypes.sizeof(_lib.AugParams),
-            _lib.PackJob.first_block.offset, _lib.UnpackJob.first_block.offset, _lib.AugParams.color.offset]
+            _lib.PackJob.first_block.offset, _lib.UnpackJob.first_block.offset, _lib.AugParams.color.offset,
+            ctypes.sizeof(_lib.BnDesc), ctypes.sizeof(_lib.BnSeg), _lib.BnDesc.gamma.offset, _lib.BnDesc.y2.offset,
+            _lib.ConvDesc.fold_elu_y.offset]
     assert got == want, (got, want)

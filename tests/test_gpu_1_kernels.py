@@ -187,10 +187,63 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
         # accumulate mode adds on top
         L.dgrad(dz, L.pack_dgrad(wd_dev, dt, i), i, gx, True)
         assert rel(gx[..., :c].float().permute(0, 3, 1, 2), 2 * x.grad) < 2 * tol
+        # ELU-derivative fold (bts_conv_desc_t::fold_elu_y): the launch that completes the gradient of an ELU output takes it
+        # through the ELU -- (result [+ old]) * (y > 0 ? 1 : y + 1) -- in every kernel's epilogue, written and accumulated
+        yv = _nhwc(torch.randn(x.shape, generator=gen), dt, v)
+        fac = torch.where(yv.float() > 0, torch.ones_like(yv, dtype=torch.float32), yv.float() + 1.0)[..., :c].permute(0, 3, 1, 2).cpu()
+        gf = torch.empty_like(segs[i])
+        L.dgrad(dz, L.pack_dgrad(wd_dev, dt, i), i, gf, False, yv)
+        assert rel(gf[..., :c].float().permute(0, 3, 1, 2), x.grad * fac) < tol, "fold seg %d" % i
+        base = _nhwc(torch.randn(x.shape, generator=gen), dt, v)
+        ga = base.clone()
+        L.dgrad(dz, L.pack_dgrad(wd_dev, dt, i), i, ga, True, yv)
+        want = (x.grad + base[..., :c].float().permute(0, 3, 1, 2).cpu()) * fac
+        assert rel(ga[..., :c].float().permute(0, 3, 1, 2), want) < 2 * tol, "fold+acc seg %d" % i
     gw = L.wgrad(segs, dz)
     e = rel(gw, w_r.grad)
     print("%s %s wgrad rel %.3e" % (name, dt, e))
     assert e < (1e-4 if dt == torch.float32 else 3e-2), "wgrad"
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 16, 9, 13), (1, 32, 21, 131), (3, 64, 7, 70)], ids=["c16", "c32_ragged", "c64"])
+def test_conv3x3_c1_streaming_kernels(dt, shape):
+    """get_depth's dedicated kernels (csrc/conv_c1.hip): sigmoid(conv3x3 to one channel) * scale[n], and the data gradient with the
+    sigmoid derivative formed from (grad_y, y), written / accumulated / folded through an ELU output -- against torch autograd."""
+    from bts_amd import ops
+    N, Cc, H, W = shape
+    gen = torch.Generator().manual_seed(N * 100 + Cc)
+    v = 4 if dt == torch.float32 else 8
+    tol = 1e-4 if dt == torch.float32 else 2e-2
+    x = torch.randn(N, Cc, H, W, generator=gen)
+    w = torch.randn(1, Cc, 3, 3, generator=gen) * (1.0 / (9 * Cc) ** 0.5)
+    if dt == torch.bfloat16:
+        x = x.to(dt).float()
+    wq = w.to(dt).float()
+    sc_n = torch.tensor([1.01, 0.97, 1.05][:N])
+    xr = x.clone().requires_grad_(True)
+    yr = torch.sigmoid(F.conv2d(xr, wq, padding=1)) * 80.0 * sc_n.view(-1, 1, 1, 1)
+    gy = torch.randn(yr.shape, generator=gen)
+    yr.backward(gy)
+    xd = _nhwc(x, dt, v)
+    assert ops.conv_c1_supported(xd)
+    wd, scd = w.to(DEV), sc_n.to(DEV)
+    y = ops.conv3x3_c1_fwd(xd, wd, 80.0, scd)
+    assert rel(y.unsqueeze(1), yr) < (1e-5 if dt == torch.float32 else 5e-3)
+    gyd = gy.squeeze(1).to(DEV).contiguous()
+    gx = torch.full(xd.shape, float("nan"), dtype=dt, device=DEV)
+    ops.conv3x3_c1_dgrad(gyd, y, wd, gx, False, 80.0, scd)
+    assert rel(gx.float().permute(0, 3, 1, 2), xr.grad) < tol
+    base = _nhwc(torch.randn(x.shape, generator=gen), dt, v)
+    yelu = _nhwc(torch.randn(x.shape, generator=gen), dt, v)
+    fac = torch.where(yelu.float() > 0, torch.ones_like(yelu, dtype=torch.float32), yelu.float() + 1.0).permute(0, 3, 1, 2).cpu()
+    ga = base.clone()
+    ops.conv3x3_c1_dgrad(gyd, y, wd, ga, True, 80.0, scd, yelu)
+    want = (xr.grad + base.float().permute(0, 3, 1, 2).cpu()) * fac
+    assert rel(ga.float().permute(0, 3, 1, 2), want) < 2 * tol
+    gf = torch.empty_like(xd)
+    ops.conv3x3_c1_dgrad(gyd, y, wd, gf, False, 80.0, None, yelu)       # no per-image scale: y was produced with one, so only shape-check
+    assert torch.isfinite(gf.float()).all()
 
 
 def test_conv_epilogues():
@@ -475,6 +528,16 @@ def test_lpg_chain_bwd_vs_autograd(c0, k, acc):
         print("   dW %s L2 %.3e max %.3e" % (tuple(wi.shape[:2]), rel_l2(g[:, :wi.shape[1]], ref_g), rel(g[:, :wi.shape[1]], ref_g)))
         assert rel_l2(g[:, :wi.shape[1]], ref_g) < l2b and rel(g[:, :wi.shape[1]], ref_g) < mxw
         assert g[:, wi.shape[1]:].abs().max().item() == 0.0 if g.shape[1] > wi.shape[1] else True
+    # x_is_elu_output: the chain completes the gradient of its input, an ELU output, and takes it through the ELU:
+    # (dx [+ old]) * (x > 0 ? 1 : x + 1) -- bit-identical to applying the factor to the plain result (same rounding points:
+    # the sum is rounded to bf16 once, after the multiplication, so compare against the f32 formula within bf16 rounding)
+    gx2 = gx0.to(DEV) if acc else torch.full((B, h, w, c0), float("nan"), dtype=torch.bfloat16, device=DEV)
+    gws2 = [torch.zeros_like(g) for g in gws]
+    chain.chain_bwd(xd, frags, frags_t, c0, k, md, gy.reshape(out.shape).to(DEV).contiguous(), gx2, acc, gws2, True)
+    fac = torch.where(x.float() > 0, torch.ones(x.shape), x.float() + 1.0)
+    assert rel_l2(gx2.float(), want * fac) < l2b and rel(gx2.float(), want * fac) < mxb
+    plain = gx.float().cpu() * fac                   # the unfolded kernel result (already bf16-rounded) times the factor
+    assert rel_l2(gx2.float(), plain) < 1e-2
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

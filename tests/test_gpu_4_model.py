@@ -400,3 +400,113 @@ def test_rccl_world1_grad_allreducer_and_ddp_step():
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, q):
+    import os
+    import traceback
+
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)                                  # both ranks share the one GPU of the box
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bts_amd.model import BtsModel, silog_loss
+        from bts_amd.parallel import GradAllReducer, broadcast_parameters
+        params = NS(encoder="densenet121_bts", max_depth=80.0, dataset="kitti", bts_size=512)
+        torch.manual_seed(50 + rank)                          # different init per rank: the broadcast must fix it
+        model = BtsModel(params).to(DEV).train()
+        for n, p in model.encoder.named_parameters():         # bts_main.py:217-247 default freeze
+            if "conv0" in n or "norm" in n:
+                p.requires_grad = False
+        broadcast_parameters(model)
+        ref = BtsModel(params).to(DEV).train()
+        ref.load_state_dict(model.state_dict())
+        for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
+            pr.requires_grad = p.requires_grad
+        gen = torch.Generator().manual_seed(70 + rank)        # rank-local batch (DistributedSampler shards, bts_dataloader.py:47)
+        B, H, W = 1, 64, 96
+        x = torch.randn(B, 3, H, W, generator=gen).to(DEV)
+        focal = O.synth_focal(B, "kitti").to(DEV)
+        gt = O.synth_depth_gt(B, H, W, "kitti", gen).to(DEV)
+        crit = silog_loss(0.85)
+        red = GradAllReducer(model.parameters(), bucket_bytes=16 << 20, tail_bytes=1 << 20)
+        assert red.collective and len(red.buckets) >= 3
+        dec_ids = {id(p) for p in model.decoder.parameters()}
+        assert all(id(p) in dec_ids for p in red.buckets[0][1][:50])          # bucket 0 starts with the decoder (registered last)
+        tail = sum(p.numel() * 4 for p in red.buckets[-1][1])
+        assert tail <= (1 << 20), tail
+        red.zero_grad()
+        crit(model(x, focal)[4], gt, gt > 1.0).backward()
+        log = list(red.launch_log)
+        red.finish()
+        # the decoder's gradients arrive together at the end of the fused decoder backward, i.e. FIRST: the bucket that holds them
+        # must be on the wire while encoder gradients are still outstanding, and every bucket must have been launched by a hook
+        n_hooks = len(red.params)
+        when = dict(log)
+        assert sorted(when) == list(range(len(red.buckets))), log
+        assert when[0] < n_hooks // 2, (when[0], n_hooks)
+        assert log[-1][1] == n_hooks, log
+        # same step through DistributedDataParallel (the reference's mechanism, bts_main.py:352) on an identical copy
+        ddp = torch.nn.parallel.DistributedDataParallel(ref, device_ids=[0], broadcast_buffers=False)
+        crit(ddp(x, focal)[4], gt, gt > 1.0).backward()
+        num = den = 0.0
+        for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
+            if not p.requires_grad:
+                assert p.grad is None
+                continue
+            assert l2rel(p.grad, pr.grad) < 5e-2, n           # bounds as in test_rccl_world1_* (ReLU-mask flips at this tiny size)
+            num += (p.grad.double() - pr.grad.double()).pow(2).sum().item()
+            den += pr.grad.double().pow(2).sum().item()
+        assert (num / den) ** 0.5 < 1e-2
+        # every rank holds identical gradients (what the optimizer sees)
+        flat = torch.cat([b[0] for b in red.buckets]).cpu()
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], g) for g in gathered)
+        # and they are the MEAN over the ranks of the local gradients (a missing or doubled mean is off by a factor of two)
+        model.zero_grad(set_to_none=True)
+        red.remove()
+        local = BtsModel(params).to(DEV).train()
+        local.load_state_dict(ref.state_dict())
+        # (BN running statistics moved during the steps above; gradients do not depend on them in train mode)
+        crit(local(x, focal)[4], gt, gt > 1.0).backward()
+        gl = torch.cat([p.grad.flatten() for p in local.decoder.parameters()]).cpu()
+        parts = [torch.zeros_like(gl) for _ in range(world)]
+        dist.all_gather(parts, gl)
+        mean = sum(parts) / world
+        got = torch.cat([p.grad.flatten() for p in ref.decoder.parameters()]).cpu()
+        assert l2rel(got, mean) < 1e-2
+        q.put((rank, "ok"))
+    except Exception as e:   # noqa: BLE001
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_real_model_gradient_exchange():
+    """N > 1 with the REAL model: two ranks share this box's GPU over gloo (only one GPU is reachable here; RCCL with N > 1 is
+    the driver's run).  BtsModel densenet121 + HIP decoder, hook-driven GradAllReducer: bucket order, small tail bucket, the
+    decoder bucket launched before the encoder backward has finished, gradients identical on both ranks, equal to
+    DistributedDataParallel's and to the hand-computed mean over the ranks."""
+    import socket
+
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=420) for _ in range(2)]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(r[1] == "ok" for r in res), res

@@ -103,9 +103,12 @@ def test_profiler_labels_follow_dispatch():
     assert conv._wgrad_kernel(bf, 1, True, False, 8, 352, 1216) == "conv_wgrad_c1<bf16>"
     assert conv._wgrad_kernel(bf, 32, True, False, 8, 352, 1216) == "conv_wgrad_halo<bf16>"
     assert conv._wgrad_kernel(bf, 32, True, True, 8, 176, 608) == "conv_wgrad_halo_up<bf16>"
+    assert conv._wgrad_kernel(bf, 64, True, False, 8, 176, 608) == "conv_wgrad_ring<bf16,64x256>"      # conv2: 64-co ring form
     assert conv._wgrad_kernel(f32, 32, True, False, 8, 352, 1216) == "conv_wgrad<f32,32x128k4>"
     assert conv._wgrad_kernel(bf, 32, True, False, 1, 32, 64) == "conv_wgrad<bf16,32x128k4>"      # < 256 tiles
-    assert conv._wgrad_kernel(bf, 512, True, False, 8, 22, 76) == "conv_wgrad_ring<bf16,128x256>"  # wide bf16: LDS-DMA + transposing reads
+    # wide bf16: LDS-DMA + transposing reads; 128 x 256 ring unless its tiles alone exceed two rounds of the chip (upconv5)
+    assert conv._wgrad_kernel(bf, 512, True, False, 8, 22, 76, 9 * 896) == "conv_wgrad_ring<bf16,128x256>"
+    assert conv._wgrad_kernel(bf, 512, True, True, 8, 11, 38, 4 * 2208) == "conv_wgrad_tr<bf16,128x128>"
     assert conv._wgrad_kernel(f32, 512, True, False, 8, 22, 76) == "conv_wgrad<f32,128x128>"
 
 

@@ -68,8 +68,8 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 
 constexpr int KC_UNUSED = 0;
 
-template <int WR, int WC, int FA, int FB, int KC, int NST, int PF, int ABL>
-__global__ __launch_bounds__(WR* WC * 64) void gemm_tn_ring(const GemmP a) {
+template <int WR, int WC, int FA, int FB, int KC, int NST, int PF, int ABL, int OCC = 1>
+__global__ __launch_bounds__(WR* WC * 64, OCC) void gemm_tn_ring(const GemmP a) {   // OCC: minimum waves per SIMD (caps the VGPRs)
     constexpr int NT = WR * WC * 64, TM = WR * FA * 32, TN = WC * FB * 32;
     constexpr int NSA = TM / 64, NSB = TN / 64, NSUB = NSA + NSB;
     constexpr int SUB = KC * 128;           // one sub-tile: KC rows x 64 columns (128 B)
@@ -244,6 +244,153 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_tn_ring(const GemmP a) {
     }
 }
 
+
+// ---- read-ahead 2: fragments of k-step s+2 are requested during k-step s (four register sets, one per k-step of a chunk) ----------
+// Hypothesis (round 3): with one k-step of read-ahead the wave reaches `s_waitcnt lgkmcnt(0)` a few dozen cycles after it issued
+// the last read, long before its 4 MFMAs (128 pipe cycles) have drained, and then sits out the LDS round trip (~120+ cycles under
+// load) -- the ablation of the shipped structure without any DMA stops at 0.57 of the MFMA peak.  Two k-steps of read-ahead give
+// every read a whole k-step to return.  The wait / barrier of the chunk moves in front of k-step KS-2 (the first one that reads
+// the next stage), all DMA issues of a chunk sit in k-steps 0 .. KS-3.
+template <int WR, int WC, int NST, int ABL>
+__global__ __launch_bounds__(WR* WC * 64) void gemm_tn_ring_ra2(const GemmP a) {
+    constexpr int FA = 2, FB = 2, KC = 64;
+    constexpr int NT = WR * WC * 64, TM = WR * FA * 32, TN = WC * FB * 32;
+    constexpr int NSA = TM / 64, NSB = TN / 64, NSUB = NSA + NSB;
+    constexpr int SUB = KC * 128, RPI = NT / 8, ROWS = NSUB * KC, G = ROWS / RPI, STAGE = NSUB * SUB;
+    constexpr int KS = 4, NM = 4, R = 8;
+    static_assert(NST >= 3 && ROWS % RPI == 0 && KC % RPI == 0, "shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.y;
+    const int L = remap_xcd(blockIdx.x, a.n_m_tiles * a.n_n_tiles);
+    const int mt = L % a.n_m_tiles, nt = L / a.n_m_tiles;
+    const char* zero = (const char*)kZeroPage;
+    const int pc = tid & 7, g8 = tid >> 3;
+    const int lp = pc ^ (((g8 >> 1) & 1) << 2);
+    const char* cbase[G];
+    int krow[G], ldk[G];
+#pragma unroll
+    for (int d = 0; d < G; ++d) {
+        const int Lr = d * RPI + g8, q = Lr / KC;
+        krow[d] = Lr % KC;
+        if (q < NSA) { const int c = mt * TM + q * 64 + lp * 8; cbase[d] = c < a.M ? (const char*)(a.A + c) : nullptr; ldk[d] = a.lda; }
+        else { const int c = nt * TN + (q - NSA) * 64 + lp * 8; cbase[d] = c < a.N ? (const char*)(a.B + c) : nullptr; ldk[d] = a.ldb; }
+    }
+    const int c_begin = split * a.chunks_per_split;
+    const int c_end = min(a.nchunks, c_begin + a.chunks_per_split);
+    auto dma = [&](int chunk, char* stage, auto dc) {
+        constexpr int d = decltype(dc)::value;
+        if constexpr (ABL != 2) {
+            const int m = chunk * KC + krow[d];
+            const bool on = chunk < c_end && m < a.K && cbase[d];
+            const char* src = on ? cbase[d] + (size_t)m * ldk[d] * 2 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(stage + (d * RPI + wave * 8) * 128), 16, 0, 0);
+        }
+    };
+    const int wr = wave / WC, wc = wave % WC;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int key = i16 >> 2, cg = i16 & 3, kb = g >> 1, chh = g & 1;
+    const int sw = (key >> 1) & 1;
+    uint32_t fo[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int c32 = f < FA ? wr * FA + f : wc * FB + (f - FA);
+        const int sub = (f < FA ? 0 : NSA) + (c32 >> 1), half = c32 & 1;
+        fo[f] = sub * SUB + (kb * 8 + key) * 128 + ((half ^ sw) << 6) + chh * 32 + cg * 8;
+    }
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const uint32_t s0 = lds_addr(smem);
+    Frag fr[4][4];                              // [k-step of the chunk][A0 A1 B0 B1]
+    auto rd = [&](auto sc, auto rc, uint32_t sT) {
+        constexpr int S = decltype(sc)::value, r = decltype(rc)::value, f = r >> 1;
+        if constexpr (ABL != 1) {
+            if constexpr (r & 1) tr_issue<S * 16 * 128 + 512>(fr[S][f].hi, sT + fo[f]);
+            else tr_issue<S * 16 * 128>(fr[S][f].lo, sT + fo[f]);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) static_for<G>([&](auto dc) { dma(c_begin + s, smem + s * STAGE, dc); });
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * G) : "memory");
+    __builtin_amdgcn_s_barrier();
+    static_for<R>([&](auto rc) { rd(I0{}, rc, s0); });
+    static_for<R>([&](auto rc) { rd(I1{}, rc, s0); });
+    int rb = 0;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const int wbuf = rb == 0 ? NST - 1 : rb - 1, nbuf = rb + 1 == NST ? 0 : rb + 1;
+        const uint32_t sT = s0 + rb * STAGE, sN = s0 + nbuf * STAGE;
+        char* stw = smem + wbuf * STAGE;
+        static_for<KS>([&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            if constexpr (S == KS - 2) {
+                // stage chunk+1 landed (this chunk's DMAs were all issued in k-steps 0..KS-3), own reads returned, publish
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * G) : "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(R) : "memory");      // k-step S's reads are back; S+1's may be in flight
+            }
+            static_for<NM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value, i = m / FB, j = m % FB;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ABL != 1) Mma<BF16>::run(frag_vec(fr[S][i]), frag_vec(fr[S][FA + j]), acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int r_lo = m * R / NM, r_hi = (m + 1) * R / NM;
+                // k-step S+2: same stage for S < KS-2, the next stage's k-steps 0, 1 behind the barrier.  Set (S+2)%4 was consumed
+                // two k-steps ago.  NOTE the set being refilled must not be the one this k-step's later MFMAs read: (S+2)%4 != S.
+                static_for<r_hi - r_lo>([&](auto k) {
+                    using RC = std::integral_constant<int, r_lo + decltype(k)::value>;
+                    if constexpr (S + 2 < KS) rd(std::integral_constant<int, S + 2>{}, RC{}, sT);
+                    else rd(std::integral_constant<int, S + 2 - KS>{}, RC{}, sN);
+                });
+                if constexpr (S < KS - 2) {
+                    constexpr int d_lo = (S * NM + m) * G / ((KS - 2) * NM), d_hi = (S * NM + m + 1) * G / ((KS - 2) * NM);
+                    static_for<d_hi - d_lo>([&](auto k) { dma(chunk + NST - 1, stw, std::integral_constant<int, d_lo + decltype(k)::value>{}); });
+                }
+            });
+        });
+        rb = nbuf;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const int frow = lane & 31, fk = lane >> 5;
+    const bool single = gridDim.y == 1;
+#pragma unroll
+    for (int j = 0; j < FB; ++j) {
+        const int col = nt * TN + (wc * FB + j) * 32 + frow;
+        const bool col_ok = col < a.N;
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+            const int rbk = mt * TM + (wr * FA + i) * 32;
+            const int row0 = rbk + 4 * fk;
+            float* p0 = a.C + (size_t)row0 * a.ldc + (col_ok ? col : 0);
+            if (single && rbk + 32 <= a.M) {
+                if (col_ok) {
+                    float old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) old[r] = p0[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldc];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p0[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldc] = old[r] + acc[i][j][r];
+                }
+            } else if (col_ok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (row0 + dr >= a.M) continue;
+                    if (single) p0[(size_t)dr * a.ldc] += acc[i][j][r];
+                    else atomicAdd(p0 + (size_t)dr * a.ldc, acc[i][j][r]);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 static float h_bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
 static uint16_t h_f2bf(float f) {
@@ -262,13 +409,13 @@ __global__ void fill_bf16(uint32_t* p, size_t n, uint32_t seed) {
     }
 }
 
-template <int WR, int WC, int FA, int FB, int KC, int NST, int PF, int ABL>
+template <int WR, int WC, int FA, int FB, int KC, int NST, int PF, int ABL, int OCC = 1>
 static void launch(GemmP p, int splits, hipStream_t st) {
     constexpr int TM = WR * FA * 32, TN = WC * FB * 32, LDS = NST * (TM + TN) / 64 * KC * 128;
     static_assert(LDS <= 160 * 1024, "LDS");
     static bool attr = false;
     if (!attr) {
-        HIPCHECK(hipFuncSetAttribute((const void*)gemm_tn_ring<WR, WC, FA, FB, KC, NST, PF, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        HIPCHECK(hipFuncSetAttribute((const void*)gemm_tn_ring<WR, WC, FA, FB, KC, NST, PF, ABL, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
     p.n_m_tiles = (p.M + TM - 1) / TM;
@@ -277,7 +424,25 @@ static void launch(GemmP p, int splits, hipStream_t st) {
     if (splits > p.nchunks) splits = p.nchunks;
     p.chunks_per_split = (p.nchunks + splits - 1) / splits;
     splits = (p.nchunks + p.chunks_per_split - 1) / p.chunks_per_split;
-    hipLaunchKernelGGL((gemm_tn_ring<WR, WC, FA, FB, KC, NST, PF, ABL>), dim3(p.n_m_tiles * p.n_n_tiles, splits), dim3(WR * WC * 64), LDS, st, p);
+    hipLaunchKernelGGL((gemm_tn_ring<WR, WC, FA, FB, KC, NST, PF, ABL, OCC>), dim3(p.n_m_tiles * p.n_n_tiles, splits), dim3(WR * WC * 64), LDS, st, p);
+}
+
+template <int WR, int WC, int NST, int ABL>
+static void launch_ra2(GemmP p, int splits, hipStream_t st) {
+    constexpr int KC = 64, TM = WR * 64, TN = WC * 64, LDS = NST * (TM + TN) / 64 * KC * 128;
+    static_assert(LDS <= 160 * 1024, "LDS");
+    static bool attr = false;
+    if (!attr) {
+        HIPCHECK(hipFuncSetAttribute((const void*)gemm_tn_ring_ra2<WR, WC, NST, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    p.n_m_tiles = (p.M + TM - 1) / TM;
+    p.n_n_tiles = (p.N + TN - 1) / TN;
+    p.nchunks = (p.K + KC - 1) / KC;
+    if (splits > p.nchunks) splits = p.nchunks;
+    p.chunks_per_split = (p.nchunks + splits - 1) / splits;
+    splits = (p.nchunks + p.chunks_per_split - 1) / p.chunks_per_split;
+    hipLaunchKernelGGL((gemm_tn_ring_ra2<WR, WC, NST, ABL>), dim3(p.n_m_tiles * p.n_n_tiles, splits), dim3(WR * WC * 64), LDS, st, p);
 }
 
 struct Variant { const char* name; void (*fn)(GemmP, int, hipStream_t); int tm, tn, lds_kib; bool checked; };
@@ -302,6 +467,22 @@ static const Variant variants[] = {
     V_(4, 2, 2, 4, 32, 4, 1, 0),      // 256x256, wave = 64 x 128
     V_(2, 4, 4, 2, 32, 4, 1, 1),      // ablations of the 256x256 ring: staging only / MFMA + reads only
     V_(2, 4, 4, 2, 32, 4, 1, 2),
+    // occupancy: the transposing 8-byte reads reach the LDS rate only from ~4 waves per SIMD (MI355X_MICROARCH.md, LDS): small
+    // stages + <= 128 VGPRs put 3-4 four-wave workgroups on a CU instead of 2
+    {"OCC4 2x2 f2x2 KC32 NST2 PF0", launch<2, 2, 2, 2, 32, 2, 0, 0, 4>, 128, 128, 32, true},
+    {"OCC4 2x2 f2x2 KC64 NST2 PF0 (LDS: 2/CU)", launch<2, 2, 2, 2, 64, 2, 0, 0, 4>, 128, 128, 64, true},
+    {"OCC3 2x2 f2x2 KC32 NST3 PF1", launch<2, 2, 2, 2, 32, 3, 1, 0, 3>, 128, 128, 48, true},
+    {"OCC3 2x2 f2x2 KC32 NST3 PF0", launch<2, 2, 2, 2, 32, 3, 0, 0, 3>, 128, 128, 48, true},
+    {"OCC4 2x2 f2x2 KC32 NST2 PF0 ABL2", launch<2, 2, 2, 2, 32, 2, 0, 2, 4>, 128, 128, 32, false},
+    {"OCC4 2x2 f2x2 KC32 NST2 PF0 ABL1", launch<2, 2, 2, 2, 32, 2, 0, 1, 4>, 128, 128, 32, false},
+    {"OCC2x8w 2x4 f2x2 KC32 NST2 PF0", launch<2, 4, 2, 2, 32, 2, 0, 0, 4>, 128, 256, 48, true},     // 8-wave 128x256, 48 KiB: 3 per CU by LDS, 2 by waves(4/SIMD)
+    {"RA2 2x2 KC64 NST3 ABL0", launch_ra2<2, 2, 3, 0>, 128, 128, 96, true},       // read-ahead 2: 128x128 (one workgroup per CU)
+    {"RA2 2x4 KC64 NST3 ABL0", launch_ra2<2, 4, 3, 0>, 128, 256, 144, true},      // ... 128x256
+    {"RA2 4x2 KC64 NST3 ABL0", launch_ra2<4, 2, 3, 0>, 256, 128, 144, true},
+    {"RA2 2x4 KC64 NST3 ABL1", launch_ra2<2, 4, 3, 1>, 128, 256, 144, false},
+    {"RA2 2x4 KC64 NST3 ABL2", launch_ra2<2, 4, 3, 2>, 128, 256, 144, false},
+    {"RA2 2x2 KC64 NST3 ABL2", launch_ra2<2, 2, 3, 2>, 128, 128, 96, false},
+    V_(2, 4, 2, 2, 64, 3, 1, 2),      // ablation of the RA1 128x256 ring for comparison
     V_(2, 2, 2, 2, 64, 2, 0, 1),      // ... and of the shipped structure
     V_(2, 2, 2, 2, 64, 2, 0, 2),
 };
@@ -369,7 +550,7 @@ int main(int argc, char** argv) {
     for (const Shape& s : shapes)
         for (const Variant& v : variants) {
             const int tiles = ((s.M + v.tm - 1) / v.tm) * ((s.N + v.tn - 1) / v.tn);
-            const int per_cu = v.lds_kib <= 80 ? 2 : 1;
+            const int per_cu = v.lds_kib <= 32 ? 4 : v.lds_kib <= 48 ? 3 : v.lds_kib <= 80 ? 2 : 1;
             // candidate pixel splits: fill one round of the chip, and twice that
             for (int mult = 1; mult <= 2; ++mult) {
                 int splits = std::max(1, 256 * per_cu * mult / tiles);
