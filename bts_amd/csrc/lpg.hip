@@ -1,10 +1,12 @@
 // Local planar guidance (LPG) kernels and the silog loss for gfx950.
 //
-// All of these are HBM-bound streaming kernels: the design rule is "one
-// thread per coarse cell, loop over the k rows of its patch", so that a wavefront touches
-// 64 consecutive cells = 64*k consecutive output floats per row (full 128-byte lines), the
-// plane coefficients / transcendentals are evaluated once per cell, and the backward
-// k*k accumulation is thread-local (no atomics, no cross-lane traffic).
+// All of these are HBM-bound streaming kernels: consecutive lanes own consecutive coarse cells, so
+// that a wavefront touches 64*k consecutive output floats per patch row (full 128-byte lines) and the plane coefficients /
+// transcendentals are evaluated once per cell.  A thread owns RPT of the k rows of its cell's patch: all of them for large
+// problems (the backward k*k accumulation is then thread-local), fewer when the map is small -- at the training shape
+// (8 x 352 x 1216) the k = 8 operator has only 53 504 cells, i.e. 209 workgroups for 256 CUs, and ran at 1.2-1.6 TB/s; with
+// one thread per (cell, row) it fills the chip (round 3).  The backward then joins the row partials of a cell through LDS
+// in a fixed order (no atomics: deterministic).
 //
 // Parity notes (bts.py:124-146): u, v are exact in f32 (k is a power of two); the
 // denominator is evaluated as ((n1*u) + (n2*v)) + n3 with every operation rounded on its
@@ -22,19 +24,26 @@ __device__ __forceinline__ float lpg_eval(float n1, float n2, float n3, float n4
 }
 
 // ---- LPG op boundary: plane_eq [B][h][w][4] -> depth [B][hk][wk] ---------------------------
-template <int K>
+// thread = (cell, group of RPT patch rows); lanes run over the cells of one coarse row
+template <int K, int RPT>
 __global__ __launch_bounds__(256) void lpg_fwd_kernel(const float* __restrict__ eq, float* __restrict__ depth,
                                                       int cells, int h, int w, float div) {
-    const int cell = blockIdx.x * 256 + threadIdx.x;
-    if (cell >= cells) return;
-    const int j = cell % w, bi = cell / w;          // bi = b*h + i
+    constexpr int NR = K / RPT;
+    const long t = blockIdx.x * 256l + threadIdx.x;
+    if (t >= (long)cells * NR) return;
+    const int j = (int)(t % w);
+    const long q = t / w;
+    const int r0 = (int)(q % NR) * RPT;
+    const long bi = q / NR;                         // bi = b*h + i
+    const long cell = bi * w + j;
     const f32x4_t e = *(const f32x4_t*)(eq + (size_t)cell * 4);
     float* out = depth + ((size_t)bi * K) * ((size_t)w * K) + (size_t)j * K;
     float u[K];
 #pragma unroll
     for (int c = 0; c < K; ++c) u[c] = lpg_offset(c, K);
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
+    for (int rr = 0; rr < RPT; ++rr) {
+        const int r = r0 + rr;
         const float v = lpg_offset(r, K);
         float o[K];
 #pragma unroll
@@ -49,45 +58,63 @@ __global__ __launch_bounds__(256) void lpg_fwd_kernel(const float* __restrict__ 
     }
 }
 
-// true gradient of out = n4 / (den * div)
-template <int K>
+// true gradient of out = n4 / (den * div).  Workgroup = (256 / NR) consecutive cells x NR row groups (thread = row group * CPB +
+// cell): each thread accumulates its RPT rows, the NR partials of a cell are summed through LDS in row order.
+template <int K, int RPT>
 __global__ __launch_bounds__(256) void lpg_bwd_kernel(const float* __restrict__ gdepth, const float* __restrict__ eq,
                                                       float* __restrict__ geq, int cells, int h, int w, float div) {
-    const int cell = blockIdx.x * 256 + threadIdx.x;
-    if (cell >= cells) return;
-    const int j = cell % w, bi = cell / w;
-    const f32x4_t e = *(const f32x4_t*)(eq + (size_t)cell * 4);
-    const float* gp = gdepth + ((size_t)bi * K) * ((size_t)w * K) + (size_t)j * K;
+    constexpr int NR = K / RPT, CPB = 256 / NR;
+    __shared__ f32x4_t part[NR > 1 ? 256 : 1];
+    const int c = threadIdx.x % CPB, rg = threadIdx.x / CPB;
+    const long cell = (long)blockIdx.x * CPB + c;
+    const bool on = cell < cells;
     float g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f;
+    if (on) {
+        const long j = cell % w, bi = cell / w;
+        const f32x4_t e = *(const f32x4_t*)(eq + (size_t)cell * 4);
+        const float* gp = gdepth + ((size_t)bi * K) * ((size_t)w * K) + (size_t)j * K;
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
-        const float v = lpg_offset(r, K);
-        float g[K];
-        const float* p = gp + (size_t)r * w * K;
-        if (K >= 4) {
+        for (int rr = 0; rr < RPT; ++rr) {
+            const int r = rg * RPT + rr;
+            const float v = lpg_offset(r, K);
+            float g[K];
+            const float* p = gp + (size_t)r * w * K;
+            if (K >= 4) {
 #pragma unroll
-            for (int c = 0; c < K; c += 4) {
-                const f32x4_t t = *(const f32x4_t*)(p + c);
-                g[c] = t.x; g[c + 1] = t.y; g[c + 2] = t.z; g[c + 3] = t.w;
+                for (int cc = 0; cc < K; cc += 4) {
+                    const f32x4_t tt = *(const f32x4_t*)(p + cc);
+                    g[cc] = tt.x; g[cc + 1] = tt.y; g[cc + 2] = tt.z; g[cc + 3] = tt.w;
+                }
+            } else {
+                const float2 tt = *(const float2*)p;
+                g[0] = tt.x; g[1] = tt.y;
             }
-        } else {
-            const float2 t = *(const float2*)p;
-            g[0] = t.x; g[1] = t.y;
-        }
 #pragma unroll
-        for (int c = 0; c < K; ++c) {
-            const float u = lpg_offset(c, K);
-            const float den = __fadd_rn(__fadd_rn(__fmul_rn(e.x, u), __fmul_rn(e.y, v)), e.z);
-            const float inv = 1.f / (den * div);
-            const float gi = g[c] * inv;          // d out / d n4 * g
-            const float gq = -gi * (e.w / den);   // d out / d den * g
-            g4 += gi;
-            g1 += gq * u;
-            g2 += gq * v;
-            g3 += gq;
+            for (int cc = 0; cc < K; ++cc) {
+                const float u = lpg_offset(cc, K);
+                const float den = __fadd_rn(__fadd_rn(__fmul_rn(e.x, u), __fmul_rn(e.y, v)), e.z);
+                const float inv = 1.f / (den * div);
+                const float gi = g[cc] * inv;         // d out / d n4 * g
+                const float gq = -gi * (e.w / den);   // d out / d den * g
+                g4 += gi;
+                g1 += gq * u;
+                g2 += gq * v;
+                g3 += gq;
+            }
         }
     }
-    *(f32x4_t*)(geq + (size_t)cell * 4) = f32x4_t{g1, g2, g3, g4};
+    if constexpr (NR == 1) {
+        if (on) *(f32x4_t*)(geq + (size_t)cell * 4) = f32x4_t{g1, g2, g3, g4};
+    } else {
+        part[threadIdx.x] = f32x4_t{g1, g2, g3, g4};
+        __syncthreads();
+        if (rg == 0 && on) {
+            f32x4_t s = part[c];
+#pragma unroll
+            for (int k2 = 1; k2 < NR; ++k2) s += part[k2 * CPB + c];
+            *(f32x4_t*)(geq + (size_t)cell * 4) = s;
+        }
+    }
 }
 
 // ---- fused head ------------------------------------------------------------------------------
@@ -357,17 +384,41 @@ __global__ __launch_bounds__(256) void silog_bwd_kernel(const float* __restrict_
     }
 }
 
+// rows per thread: the whole patch when that already gives >= 2^19 threads (two full waves of workgroups per CU), else the
+// largest split that does, else one row per thread
 template <int K>
-int lpg_fwd_launch(const float* eq, float* depth, int cells, int h, int w, float div, hipStream_t st) {
-    hipLaunchKernelGGL(lpg_fwd_kernel<K>, dim3(ceil_div(cells, 256)), dim3(256), 0, st, eq, depth, cells, h, w, div);
+int lpg_rows_per_thread(int cells) {
+    int rpt = K;
+    while (rpt > 1 && (long)cells * (K / rpt) < (1l << 19)) rpt >>= 1;
+    return rpt;
+}
+template <int K, int RPT>
+int lpg_fwd_go(const float* eq, float* depth, int cells, int h, int w, float div, hipStream_t st) {
+    hipLaunchKernelGGL((lpg_fwd_kernel<K, RPT>), dim3(ceil_div((long)cells * (K / RPT), 256)), dim3(256), 0, st, eq, depth, cells, h, w, div);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+template <int K, int RPT>
+int lpg_bwd_go(const float* g, const float* eq, float* geq, int cells, int h, int w, float div, hipStream_t st) {
+    hipLaunchKernelGGL((lpg_bwd_kernel<K, RPT>), dim3(ceil_div(cells, 256 / (K / RPT))), dim3(256), 0, st, g, eq, geq, cells, h, w, div);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }
 template <int K>
+int lpg_fwd_launch(const float* eq, float* depth, int cells, int h, int w, float div, hipStream_t st) {
+    const int rpt = lpg_rows_per_thread<K>(cells);
+    if constexpr (K >= 8) { if (rpt == 8) return lpg_fwd_go<K, 8>(eq, depth, cells, h, w, div, st); }
+    if constexpr (K >= 4) { if (rpt == 4) return lpg_fwd_go<K, 4>(eq, depth, cells, h, w, div, st); }
+    if (rpt == 2) return lpg_fwd_go<K, 2>(eq, depth, cells, h, w, div, st);
+    return lpg_fwd_go<K, 1>(eq, depth, cells, h, w, div, st);
+}
+template <int K>
 int lpg_bwd_launch(const float* g, const float* eq, float* geq, int cells, int h, int w, float div, hipStream_t st) {
-    hipLaunchKernelGGL(lpg_bwd_kernel<K>, dim3(ceil_div(cells, 256)), dim3(256), 0, st, g, eq, geq, cells, h, w, div);
-    BTS_LAUNCH_CHECK();
-    return BTS_OK;
+    const int rpt = lpg_rows_per_thread<K>(cells);
+    if constexpr (K >= 8) { if (rpt == 8) return lpg_bwd_go<K, 8>(g, eq, geq, cells, h, w, div, st); }
+    if constexpr (K >= 4) { if (rpt == 4) return lpg_bwd_go<K, 4>(g, eq, geq, cells, h, w, div, st); }
+    if (rpt == 2) return lpg_bwd_go<K, 2>(g, eq, geq, cells, h, w, div, st);
+    return lpg_bwd_go<K, 1>(g, eq, geq, cells, h, w, div, st);
 }
 
 }  // namespace

@@ -43,19 +43,20 @@ def npix(t):
 # ---------------------------------------------------------------------------------------------
 # LPG op boundary (TF-op layout): plane_eq [B,h,w,4] f32 -> depth [B,h*k,w*k] f32
 # ---------------------------------------------------------------------------------------------
-def lpg_fwd(plane_eq, k, depth_div=1.0, focal=None):
+def lpg_fwd(plane_eq, k, depth_div=1.0, focal=None, out=None):
     _lib.require_gpu(plane_eq)
     B, h, w, four = plane_eq.shape
     assert four == 4 and plane_eq.dtype == torch.float32 and plane_eq.is_contiguous()
-    out = torch.empty((B, h * k, w * k), dtype=torch.float32, device=plane_eq.device)
+    if out is None:
+        out = torch.empty((B, h * k, w * k), dtype=torch.float32, device=plane_eq.device)
     call("bts_lpg_fwd", _p(plane_eq), _p(focal), _p(out), B, h, w, k, float(depth_div), stream_ptr())
     return out
 
 
-def lpg_bwd(grad_depth, plane_eq, k, depth_div=1.0, focal=None):
+def lpg_bwd(grad_depth, plane_eq, k, depth_div=1.0, focal=None, out=None):
     B, h, w, _ = plane_eq.shape
     grad_depth = grad_depth.contiguous()
-    g = torch.empty_like(plane_eq)
+    g = torch.empty_like(plane_eq) if out is None else out
     call("bts_lpg_bwd", _p(grad_depth), _p(plane_eq), _p(focal), _p(g), B, h, w, k, float(depth_div), stream_ptr())
     return g
 

@@ -7,7 +7,10 @@ Input: the two rocprofv3 counter-collection CSVs of the SAME bench command, one 
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out/f -o b -- python bench.py --graph 0 --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out/w -o b -- python bench.py --graph 0 --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events
-    python tools/pmc_traffic.py out/f/b_counter_collection.csv out/w/b_counter_collection.csv profiles/pmc_traffic.json
+    python tools/pmc_traffic.py out/f/b_counter_collection.csv out/w/b_counter_collection.csv profiles/pmc_traffic.json [libbts_amd.so md5]
+
+The md5 of the profiled library goes into the file's `_meta` entry: bench.py only reports these figures as `roofline.traffic`
+when it is timing the same binary (otherwise under `traffic_archived`).
 
 Units and corrections: both counters are reported in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide
 coalesced reads at 64 B, so it is doubled (same guide, HBM section); WRITE_SIZE is taken as is (uncalibrated there).
@@ -28,8 +31,25 @@ def family(name):
     if m:
         wr, wc, tm, tn = map(int, m.groups())
         return "conv_igemm_dma<bf16,%dx%d>" % (wr * tm * 32, wc * tn * 32)
+    m = re.match(r"conv_wgrad_ring<(\d), (\d)", n)
+    if m:
+        return "conv_wgrad_ring<bf16,%dx%d>" % (int(m.group(1)) * 64, int(m.group(2)) * 64)
     if n.startswith("conv_wgrad_tr"):
         return "conv_wgrad_tr<bf16,128x128>"
+    if n.startswith("conv_halo_wide"):
+        return "conv_halo_wide<bf16,128x256>"
+    if n.startswith("conv_c1_fwd"):
+        return "conv_c1_fwd"
+    if n.startswith("conv_c1_dgrad"):
+        return "conv_c1_dgrad"
+    if n.startswith("conv_wgrad_c1"):
+        return "conv_wgrad_c1<bf16>"
+    if n.startswith("bn_bwd_"):
+        return "bn_bwd"
+    if n.startswith("bn_apply_ms"):
+        return "bn_apply"
+    if n.startswith("bn_stats_"):
+        return "bn_stats"
     if n.startswith("conv_halo<BF16"):
         return "conv_halo<bf16>"
     if n.startswith("conv_wgrad_halo_up"):
@@ -54,6 +74,7 @@ def load(path, counter):
 
 def main():
     fpath, wpath, out = sys.argv[1:4]
+    md5 = sys.argv[4] if len(sys.argv) > 4 else None
     fetch, write = load(fpath, "FETCH_SIZE"), load(wpath, "WRITE_SIZE")
     table = {}
     for fam in sorted(set(fetch) & set(write)):
@@ -64,9 +85,13 @@ def main():
                       "launches_fetch_pass": nf, "launches_write_pass": nw,
                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --graph 0; FETCH_SIZE x2 "
                                 "(gfx950 tallies 128-B requests at 64 B), KiB -> bytes; fabric-side, Infinity-Cache hits included"}
+    table["_meta"] = {"library_md5": md5, "note": "bn_bwd = reduction + final + apply kernels of one call, bn_stats = partial + final: "
+                      "per KERNEL launch here, where bench.py's families count C-ABI calls"}
     with open(out, "w") as f:
         json.dump(table, f, indent=1)
     for k, v in table.items():
+        if k.startswith("_"):
+            continue
         print("%-32s %8.1f MB/launch (read %.1f, write %.1f) over %d launches" % (k, v["bytes_per_launch"] / 1e6, v["read_bytes_per_launch"] / 1e6,
                                                                                v["write_bytes_per_launch"] / 1e6, v["launches_fetch_pass"]))
 
