@@ -190,6 +190,8 @@ def attach_traffic(roof):
         if same:
             r["traffic"] = ent.get("bytes_per_launch")
             r["traffic_source"] = "%s; library md5 %s = the binary timed here" % (ent.get("source"), meta.get("library_md5"))
+            if meta.get("config"):
+                r["traffic_config"] = meta["config"]
         else:
             r["traffic_archived"] = {"bytes_per_launch": ent.get("bytes_per_launch"), "library_md5": meta.get("library_md5"),
                                      "note": "PMC passes of an EARLIER build of libbts_amd.so: not a measurement of this run"}
