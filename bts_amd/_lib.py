@@ -100,6 +100,7 @@ SIGNATURES = {
     "bts_conv_wgrad": [C.POINTER(ConvDesc), _p, _i, _p, _p],
     "bts_conv3x3_c1_fwd": [_p, _i, _i, _i, _p, _p, _i, _i, _i, _f, _p, _p],
     "bts_conv3x3_c1_dgrad": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _f, _p, _p],
+    "bts_conv3x3_c1_wgrad": [_p, _p, _p, _i, _i, _i, _p, _i, _i, _i, _i, _f, _p, _p],
     "bts_pack_weight": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p, _p],
     "bts_unpack_wgrad": [_p, _i, _i, _i, _p, _i, _i, _p, _p, _i, _p],
     "bts_pack_weight_batch": [_p, _i, _l, _i, _p],

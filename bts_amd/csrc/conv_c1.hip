@@ -11,7 +11,12 @@
 //
 // so they are written as such: 16-byte accesses that cover whole pixel rows (a wave moves 4 KiB of consecutive bytes), the
 // 3x3 window from an LDS patch staged once per tile, bf16 products on v_dot2c_f32_bf16 (two MACs per lane-op, no unpacking),
-// f32 accumulation.  The weight gradient stays with conv_wgrad_c1 (conv_igemm.hip), which already has this form.
+// f32 accumulation.  The weight gradient (further down) is the same streaming form; the sigmoid derivative is formed inside the
+// two backward kernels from (grad_y, y), so no dz map is written or read.
+// Isolated, back-to-back at 8 x 352 x 1216 x 32 bf16 (tools/c1_bench.py, gpurun r03ac/r03ad): forward 78-81 us (first form: 105),
+// data gradient 51 us plain / 143 us accumulating + ELU fold (4.8 TB/s of algorithmic bytes either way), weight gradient 88 us.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -89,6 +94,110 @@ __global__ __launch_bounds__(TH* TW) void conv_c1_fwd_kernel(const void* __restr
         float sc = out_scale;
         if (out_scale_n) sc *= out_scale_n[n];
         y[((size_t)n * H + oy) * W + ox] = act_sigmoid(acc) * sc;
+    }
+}
+
+// ---- forward, second form (r3) ---------------------------------------------------------------------------------------------------------
+// The form above reads every pixel's 64 B nine times from the LDS patch plus nine broadcast weight vectors: 1152 B of LDS reads per
+// output pixel, ~50 us of LDS time at 8 x 352 x 1216 behind an un-overlapped staging phase (117 us measured for 219 MB).  Here the
+// sum is split the other way round:  s_t[q] = x[q] . w[t]  (nine dot products per INPUT pixel, x straight from global memory into
+// registers, each 16-byte vector read exactly once and never staged),  y[p] = sigmoid(sum_t s_t[p + t]) * scale  (nine scalars per
+// output pixel through LDS: 36 B written + 36 B read per pixel).  Thread = (pixel lane, 16-byte channel vector) with its 9 x V
+// weights in registers; the partial dot products of a pixel's CV lanes meet by DPP (quad) / bpermute butterflies.
+template <typename T, int TH, int TW>
+__global__ __launch_bounds__(256) void conv_c1_fwd2_kernel(const void* __restrict__ x, int xs, int C, const float* __restrict__ w,
+                                                           float* __restrict__ y, int N, int H, int W, float out_scale,
+                                                           const float* __restrict__ out_scale_n) {
+    constexpr int V = T::kVec, ES = T::kBytes, PW = TW + 2, PH = TH + 2, PR = PH * PW;
+    constexpr int WD = ES == 2 ? V / 2 : V;                           // dwords of weights per (tap, vector)
+    constexpr int NU = 4;                                             // independent 16-byte loads in front of the arithmetic
+    __shared__ float S[9 * PR];
+    __shared__ float sw[9 * 64];
+    const int tid = threadIdx.x;
+    const int CV = C / V;                                             // power of two <= 16 (launcher)
+    const int cv = tid & (CV - 1), pl = tid / CV, NPL = 256 / CV;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    int tile = blockIdx.x;
+    const int tx0 = (tile % tiles_x) * TW;
+    tile /= tiles_x;
+    const int ty0 = (tile % tiles_y) * TH, n = tile / tiles_y;
+    for (int i = tid; i < 9 * C; i += 256) {
+        const int t = i / C, c = i - t * C;
+        sw[i] = w[c * 9 + t];
+    }
+    __syncthreads();
+    uint32_t wr[9][WD];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int d = 0; d < WD; ++d) {
+            if (ES == 2) wr[t][d] = pack_bf16x2(sw[t * C + cv * V + 2 * d], sw[t * C + cv * V + 2 * d + 1]);   // RNE, as bts_pack_weight
+            else wr[t][d] = __float_as_uint(sw[t * C + cv * V + d]);
+        }
+    for (int i0 = pl; i0 < PR; i0 += NU * NPL) {
+        u32x4_t raw[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int i = i0 + u * NPL;
+            const int py = i / PW, px = i - py * PW;
+            const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+            raw[u] = u32x4_t{0u, 0u, 0u, 0u};
+            if (i < PR && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                raw[u] = *(const u32x4_t*)((const char*)x + ((((size_t)n * H + iy) * W + ix) * (size_t)xs + cv * V) * ES);
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int i = i0 + u * NPL;
+            float st[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float acc = 0.f;
+                if (ES == 2) {
+                    acc = dot2_bf16(raw[u].x, wr[t][0], acc);
+                    acc = dot2_bf16(raw[u].y, wr[t][1], acc);
+                    acc = dot2_bf16(raw[u].z, wr[t][2], acc);
+                    acc = dot2_bf16(raw[u].w, wr[t][3], acc);
+                } else {
+                    acc = fmaf(__uint_as_float(raw[u].x), __uint_as_float(wr[t][0]), acc);
+                    acc = fmaf(__uint_as_float(raw[u].y), __uint_as_float(wr[t][1]), acc);
+                    acc = fmaf(__uint_as_float(raw[u].z), __uint_as_float(wr[t][2]), acc);
+                    acc = fmaf(__uint_as_float(raw[u].w), __uint_as_float(wr[t][3]), acc);
+                }
+                st[t] = acc;
+            }
+            // butterfly over the CV lanes of the pixel (they are adjacent: cv = tid % CV)
+            if (CV >= 2) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    st[t] += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(st[t]), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+            }
+            if (CV >= 4) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    st[t] += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(st[t]), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+            }
+            for (int m = 4; m < CV; m <<= 1) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) st[t] += __shfl_xor(st[t], m);
+            }
+            // every lane of the pixel now holds all nine sums; lane cv stores taps cv, cv + CV, ...
+            if (i < PR) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    if ((t & (CV - 1)) == cv) S[t * PR + i] = st[t];
+            }
+        }
+    }
+    __syncthreads();
+    float sc = out_scale;
+    if (out_scale_n) sc *= out_scale_n[n];
+    for (int p = tid; p < TH * TW; p += 256) {
+        const int ly = p / TW, lx = p - ly * TW;
+        const int oy = ty0 + ly, ox = tx0 + lx;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc += S[t * PR + (ly + t / 3) * PW + lx + t % 3];
+        if (oy < H && ox < W) y[((size_t)n * H + oy) * W + ox] = act_sigmoid(acc) * sc;
     }
 }
 
@@ -174,6 +283,123 @@ __global__ __launch_bounds__(256) void conv_c1_dgrad_kernel(const float* __restr
     }
 }
 
+// ---- weight gradient ---------------------------------------------------------------------------------------------------------------
+//     dW[t][c] = sum_q x[q][c] * dz[q - tap_t],   dz = gy * scale * s (1 - s)   (as the data gradient above)
+// Thread = (pixel lane, 16-byte channel vector) as in the data gradient; a workgroup walks a contiguous range of 8 x 64 tiles (the
+// dz patch of the next tile is formed from (gy, y) in registers while this tile's x vectors stream), keeps its 9 x V partial
+// sums in registers over the whole range and reduces them once: butterfly over the pixel lanes of a wave, LDS over the four waves,
+// one set of 9 x C atomics per workgroup.  x is read exactly once, in 1-KiB runs per wave; no dz map is materialised (the first
+// version -- conv_wgrad_c1 in conv_igemm.hip behind a separate sigmoid-derivative pass that wrote dz as a strided bf16 map -- took
+// 164 + 22 us at 8 x 352 x 1216 for 219 MB of x: 1.2 TB/s).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ yv,
+                                                            const void* __restrict__ x, int xs, int C, float* dw, int ktot, int N, int H,
+                                                            int W, float out_scale, const float* __restrict__ out_scale_n) {
+    constexpr int V = T::kVec, ES = T::kBytes, TH = 8, TW = 64, PW = TW + 2, PH = TH + 2, PR = PH * PW, NLD = (PR + 255) / 256;
+    __shared__ float sdz[2][PR];
+    __shared__ float red[4 * 16 * 9 * V];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int CV = C / V;                                             // power of two <= 16 (launcher)
+    const int cv = tid & (CV - 1), pl = tid / CV, NPL = 256 / CV;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * N;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
+    if (t_begin >= t_end) return;
+    auto origin = [&](int tile, int& n, int& y0, int& x0) {
+        const int tx = tile % tiles_x, r1 = tile / tiles_x;
+        y0 = (r1 % tiles_y) * TH; n = r1 / tiles_y; x0 = tx * TW;
+    };
+    auto load_dz = [&](int tile, float (&g)[NLD]) {                   // zeros outside the image: the convolution's padding
+        int n, y0, x0;
+        origin(tile, n, y0, x0);
+        float sc = out_scale;
+        if (out_scale_n) sc *= out_scale_n[n];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j;
+            const int py = i / PW, px = i - py * PW;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            g[j] = 0.f;
+            if (i < PR && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                const size_t o = ((size_t)n * H + iy) * W + ix;
+                const float sg = yv[o] / sc;
+                g[j] = gy[o] * sc * sg * (1.f - sg);
+            }
+        }
+    };
+    auto store_dz = [&](float* dst, const float (&g)[NLD]) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            if (tid + 256 * j < PR) dst[tid + 256 * j] = g[j];
+    };
+    float acc[9][V];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[t][e] = 0.f;
+    float gnext[NLD];
+    load_dz(t_begin, gnext);
+    store_dz(sdz[0], gnext);
+    __syncthreads();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int cur = (tile - t_begin) & 1;
+        int n, y0, x0;
+        origin(tile, n, y0, x0);
+        if (tile + 1 < t_end) load_dz(tile + 1, gnext);              // in flight under this tile's x vectors
+        for (int p0 = pl; p0 < TH * TW; p0 += 4 * NPL) {
+            u32x4_t raw[4];
+            int qy[4], qx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                             // four independent 16-byte loads in front of the arithmetic
+                const int p = p0 + u * NPL < TH * TW ? p0 + u * NPL : 0;          // (beyond the tile: a zero vector against cell 0)
+                const bool live = p0 + u * NPL < TH * TW;
+                qy[u] = p / TW; qx[u] = p - qy[u] * TW;
+                const int iy = y0 + qy[u], ix = x0 + qx[u];
+                raw[u] = u32x4_t{0u, 0u, 0u, 0u};
+                if (live && iy < H && ix < W)
+                    raw[u] = *(const u32x4_t*)((const char*)x + ((((size_t)n * H + iy) * W + ix) * (size_t)xs + cv * V) * ES);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[V];
+                T::unpack(raw[u], f);
+                // x[q] meets dz[q - tap]: tap (ky, kx) has offset (ky-1, kx-1) -> patch cell (qy+1-(ky-1), qx+1-(kx-1))
+                const float* gz = sdz[cur] + (qy[u] + 2) * PW + qx[u] + 2;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float d = gz[-(t / 3) * PW - (t % 3)];
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[t][e] = fmaf(d, f[e], acc[t][e]);
+                }
+            }
+        }
+        if (tile + 1 < t_end) store_dz(sdz[cur ^ 1], gnext);
+        __syncthreads();
+    }
+    // pixel lanes of a wave: lanes that share cv differ in the bits above log2(CV)
+    for (int m = CV; m < 64; m <<= 1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[t][e] += __shfl_xor(acc[t][e], m);
+    }
+    if (lane < CV) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < V; ++e) red[((wave * 16 + cv) * 9 + t) * V + e] = acc[t][e];
+    }
+    __syncthreads();
+    for (int i = tid; i < CV * 9 * V; i += 256) {
+        const int e = i % V, t = (i / V) % 9, c = i / (9 * V);
+        float sum = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) sum += red[((w4 * 16 + c) * 9 + t) * V + e];
+        atomicAdd(dw + (size_t)t * ktot + c * V + e, sum);
+    }
+}
+
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 }  // namespace
@@ -185,6 +411,22 @@ extern "C" int bts_conv3x3_c1_fwd(const void* x, int dtype, int x_stride, int C,
     BTS_CHECK_ARG(C > 0 && C % V == 0 && x_stride >= C && x_stride % V == 0 && ((uintptr_t)x & 15) == 0);
     if (C * ES > 256) return BTS_ERR_UNSUPPORTED;                      // wider inputs: the MFMA path (bts_conv_fwd)
     hipStream_t st = (hipStream_t)stream;
+    // BTS_C1_FWD=1: the first form (LDS patch, thread = output pixel) for A/B; default: the second form where its domain allows
+    static const int form = [] { const char* e = getenv("BTS_C1_FWD"); return e ? atoi(e) : 2; }();
+    if (form >= 2 && pow2(C / V) && C / V <= 16 && C <= 64) {
+        // 16 x 64 tiles, 45 KiB of LDS (3 workgroups per CU).  8 x 64 (24 KiB, 6 per CU) and 2 / 4 loads in flight per thread measured
+        // the same within 2 % (gpurun r03ad: 76-81 us bf16): the kernel is bound by its ~125 VALU operations per input vector.
+        constexpr int TH = 16, TW = 64;
+        const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+        if (dtype == BTS_BF16)
+            hipLaunchKernelGGL((conv_c1_fwd2_kernel<BF16, TH, TW>), dim3((unsigned)tiles), dim3(256), 0, st, x, x_stride, C, w, y, N, H, W,
+                               out_scale, out_scale_n);
+        else
+            hipLaunchKernelGGL((conv_c1_fwd2_kernel<F32, TH, TW>), dim3((unsigned)tiles), dim3(256), 0, st, x, x_stride, C, w, y, N, H, W,
+                               out_scale, out_scale_n);
+        BTS_LAUNCH_CHECK();
+        return BTS_OK;
+    }
     const int pitch = C * ES + 16;
     if (dtype == BTS_BF16) {
         constexpr int TH = 4, TW = 64;
@@ -226,6 +468,28 @@ extern "C" int bts_conv3x3_c1_dgrad(const float* grad_y, const float* y, const f
     if (dtype == BTS_F32) LA_(F32); else LA_(BF16);
 #undef LA_
 #undef L_
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_conv3x3_c1_wgrad(const float* grad_y, const float* y, const void* x, int dtype, int x_stride, int C, float* dw,
+                                    int dw_ktot, int N, int H, int W, float out_scale, const float* out_scale_n, bts_stream_t stream) {
+    BTS_CHECK_ARG(grad_y && y && x && dw && N > 0 && H > 0 && W > 0 && (dtype == BTS_F32 || dtype == BTS_BF16) && out_scale > 0.f);
+    const int V = dtype == BTS_F32 ? 4 : 8;
+    BTS_CHECK_ARG(C > 0 && C % V == 0 && x_stride >= C && x_stride % V == 0 && ((uintptr_t)x & 15) == 0 && dw_ktot >= C);
+    const int CV = C / V;
+    if (!pow2(CV) || CV > 16 || C > 64) return BTS_ERR_UNSUPPORTED;
+    const long tiles = (long)N * ((H + 7) / 8) * ((W + 63) / 64);
+    static const int per_cu_env = [] { const char* e = getenv("BTS_C1_WGRAD_PERCU"); return e ? atoi(e) : 0; }();   // A/B knob
+    const long per_cu = per_cu_env > 0 ? per_cu_env : dtype == BTS_F32 ? 4 : 3;         // 110 / 164 VGPRs: waves per SIMD
+    const long wgs = tiles < per_cu * bts_cu_count() ? tiles : per_cu * bts_cu_count();
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == BTS_F32)
+        hipLaunchKernelGGL(conv_c1_wgrad_kernel<F32>, dim3((unsigned)wgs), dim3(256), 0, st, grad_y, y, x, x_stride, C, dw, dw_ktot, N, H, W,
+                           out_scale, out_scale_n);
+    else
+        hipLaunchKernelGGL(conv_c1_wgrad_kernel<BF16>, dim3((unsigned)wgs), dim3(256), 0, st, grad_y, y, x, x_stride, C, dw, dw_ktot, N, H, W,
+                           out_scale, out_scale_n);
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }

@@ -56,6 +56,7 @@ struct ConvK {
     int n_col_tiles, nchunks, chunks_per_split;
     int halo_ok;   // every tap within radius 1 on an unscaled same-size input: eligible for conv_halo
     int kmajor;    // conv_igemm_dma K order: 1 = channel chunk outer, taps inner (needs KV % 8 == 0); 0 = tap outer
+    int halo_regw; // conv_halo, one-chunk 9-tap layers with <= 3 k-steps: weight fragments live in registers (BTS_HALO_REGW=0: A/B)
 };
 
 // The strength-reduced address paths multiply (pixel index) x (pixel stride in bytes) in 32 bits: a launcher that uses them

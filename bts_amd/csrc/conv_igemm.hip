@@ -782,12 +782,89 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
         }
     };
 
+    // Register-resident weights (r3).  Above, every MFMA costs TWO 1-KiB LDS reads (its weight and its pixel fragment): four SIMDs
+    // retire an MFMA every 8 clk between them, the LDS delivers 128 B/clk, so the pair needs 16 clk -- the narrow layers sat at
+    // 0.44 of the executed MFMA rate with the LDS pipe as the limiter.  When the whole K is one chunk of <= 48 channels (conv1 and
+    // its data-gradients: 9 taps x <= 3 k-steps) the 27 weight fragments of a lane fit its registers (108 VGPRs), are read ONCE
+    // per workgroup, and the tile loop reads pixel fragments only: one LDS read per MFMA.
+    auto compute_rw = [&](const char* sP, f32x16_t& acc, const auto& faR, auto nks_c) {
+        constexpr int NKS = decltype(nks_c)::value, NQ = NT * NKS, D = 3;
+        uint32_t sPa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)sP;
+        asm volatile("" : "+v"(sPa));
+        auto rd = [&](u32x4_t& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); };
+        u32x4_t fb[D + 1];
+        static_for_n<(D < NQ ? D : NQ)>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            rd(fb[q], sPa + pb_off(q / NKS, q % NKS));
+        });
+        static_for_n<NQ>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            if constexpr (q + D < NQ) {
+                rd(fb[(q + D) % (D + 1)], sPa + pb_off((q + D) / NKS, (q + D) % NKS));
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(D) : "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NQ - 1 - q) : "memory");      // the reads still behind this one
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            Mma<T>::run(faR[q / NKS][q % NKS], fb[q % (D + 1)], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
     if constexpr (PERSIST) {
         // K fits one channel chunk: the weights stay in LDS for the whole workgroup, which walks a contiguous range
         // of tiles with double-buffered patches (the DMA of tile i+1 is in flight under the MFMAs + stores of tile i).
         const int per = (ntiles + gridDim.x - 1) / gridDim.x;
         const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
         if (t_begin >= t_end) return;
+        const int nks_all = (min(a.KV, 8) + 1) >> 1;
+        // (r3, gpurun r03ab: a counted per-tile wait that leaves the previous tile's output stores in flight -- they are younger than
+        // the patch DMA in plain launches -- changes nothing, 0-1 % on every layer: the store latency is not what the loop waits for.)
+        if constexpr (FULLTAB && NG == 1) {
+            if (a.halo_regw && nks_all <= 3) {
+                // same pipeline as below (see there), with the weight fragments lifted into registers behind the first barrier
+                auto run_tiles = [&](auto nks_c) {
+                    constexpr int NKS = decltype(nks_c)::value;
+                    dma_weights(0);
+                    int n, y0, x0;
+                    tile_origin(t_begin, n, y0, x0);
+                    dma_patch(0, n, y0, x0, smem);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    u32x4_t faR[NT][NKS];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int s2 = 0; s2 < NKS; ++s2) faR[t][s2] = *(const u32x4_t*)(sW + t * 32 * 128 + wA[s2]);
+                    int n1 = 0, y1 = 0, x1 = 0;
+                    if (t_begin + 1 < t_end) {
+                        tile_origin(t_begin + 1, n1, y1, x1);
+                        dma_patch(0, n1, y1, x1, smem + PR_PAD * 128);
+                    }
+                    for (int tile = t_begin; tile < t_end; ++tile) {
+                        const int cur = (tile - t_begin) & 1;
+                        f32x16_t acc[NG];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+                        compute_rw(smem + cur * PR_PAD * 128, acc[0], faR, nks_c);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                        int n2 = 0, y2 = 0, x2 = 0;
+                        const bool more = tile + 2 < t_end;
+                        if (more) tile_origin(tile + 2, n2, y2, x2);
+                        if (more && !(a.accumulate || a.fold_y)) dma_patch(0, n2, y2, x2, smem + cur * PR_PAD * 128);
+                        epilogue(acc, n, y0, x0);
+                        if (more && (a.accumulate || a.fold_y)) dma_patch(0, n2, y2, x2, smem + cur * PR_PAD * 128);
+                        n = n1; y0 = y1; x0 = x1;
+                        n1 = n2; y1 = y2; x1 = x2;
+                    }
+                };
+                if (nks_all == 1) run_tiles(std::integral_constant<int, 1>());
+                else if (nks_all == 2) run_tiles(std::integral_constant<int, 2>());
+                else run_tiles(std::integral_constant<int, 3>());
+                return;
+            }
+        }
         // Pipeline (r2).  State at the top of iteration i: patch i has landed and is published, the DMA of patch i+1 is in
         // flight into the other buffer.  compute(i); then ONE wait + barrier: the wait retires this wave's pieces of patch i+1
         // (issued a whole iteration ago) and the output stores of tile i-1 (issued a whole compute() ago), the barrier publishes
@@ -813,7 +890,7 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
             for (int g = 0; g < NG; ++g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-            compute(smem + cur * PR_PAD * 128, acc, (min(a.KV, 8) + 1) >> 1);
+            compute(smem + cur * PR_PAD * 128, acc, nks_all);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                         // patch tile+1 landed everywhere; buffer `cur` is free
             int n2 = 0, y2 = 0, x2 = 0;
@@ -1784,6 +1861,8 @@ static int fill_common(const bts_conv_desc_t* d, ConvK& k) {
     }
     k.Cout = d->Cout;
     k.Hy = d->Hy; k.Wy = d->Wy; k.osc = d->osc;
+    static const int regw_on = [] { const char* e = getenv("BTS_HALO_REGW"); return (e && e[0] == '0') ? 0 : 1; }();
+    k.halo_regw = regw_on;
     k.halo_ok = d->isc == 1 && d->Hx == d->Hg && d->Wx == d->Wg &&
                 ((d->nphase == 1 && d->T == 9 && d->osc == 1) || (d->nphase == 4 && d->T == 4 && d->osc == 2));
     for (int t = 0; t < k.Ttot && k.halo_ok; ++t)

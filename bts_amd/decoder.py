@@ -298,8 +298,8 @@ class DecoderRun:
 
     def conv_c1(self, name, x, out_scale, out_scale_n):
         """3x3 convolution to one channel + sigmoid * scale (get_depth, bts.py:193-194, 262-264) on the streaming kernels of
-        csrc/conv_c1.hip: forward and data gradient; the weight gradient stays with conv_wgrad_c1.  Falls back to the generic
-        convolution outside their domain."""
+        csrc/conv_c1.hip: forward, data gradient and weight gradient (the sigmoid derivative is formed inside the two backward
+        kernels; no dz map exists).  Falls back to the generic convolution outside their domain."""
         L = self.plan.layers[name]
         if not (USE_CONV_C1 and L.cout == 1 and L.kk == 9 and L.dil == 1 and not L.up and ops.conv_c1_supported(x.t)):
             return self.conv(name, [x], ACT_SIGMOID, out_map=True, out_scale=out_scale, out_scale_n=out_scale_n)
@@ -316,10 +316,9 @@ class DecoderRun:
                 ops.conv3x3_c1_dgrad(y.g, y.t, w, x.g, acc, out_scale, out_scale_n, x.t if fold else None)
                 if fold:
                     x.g_is_dz = True
-                dz = ops.act_bwd(y.g, y.t, ACT_SIGMOID, out_dtype=self.dtype, out_channels=self.v, y_scale=out_scale,
-                                 y_scale_n=out_scale_n)
                 off, shape = self.packs.dwp_off[name]
-                L.wgrad_packed([x.t], dz, self.dwp_arena[off:off + shape[0] * shape[1] * shape[2]].view(shape))
+                ops.conv3x3_c1_wgrad(y.g, y.t, x.t, self.dwp_arena[off:off + shape[0] * shape[1] * shape[2]].view(shape),
+                                     out_scale, out_scale_n)
             self.tape.append(bwd)
         return y
 

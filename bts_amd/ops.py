@@ -163,6 +163,19 @@ def conv3x3_c1_dgrad(grad_y, y, w, gx, accumulate, out_scale, out_scale_n=None, 
     return gx
 
 
+def conv3x3_c1_wgrad(grad_y, y, x, dwp, out_scale, out_scale_n=None):
+    """dwp [1, 9, Ktot] f32 (packed weight-gradient layout, caller-zeroed) += weight gradient of conv3x3_c1_fwd; the sigmoid
+    derivative is formed in the kernel from (grad_y, y)."""
+    N, H, W, Cc = x.shape
+    if dwp.dim() != 3 or dwp.shape[0] != 1 or dwp.shape[1] != 9 or dwp.shape[2] < Cc or dwp.dtype != torch.float32:
+        raise BtsAmdError("conv3x3_c1_wgrad: dwp must be f32 [1, 9, Ktot >= C], got %s %s" % (tuple(dwp.shape), dwp.dtype))
+    if profiler.ACTIVE is not None:
+        profiler.note("conv_c1_wgrad", "hbm", N * H * W * (8 + Cc * x.element_size()), "get_depth.wgrad")
+    call("bts_conv3x3_c1_wgrad", _p(grad_y), _p(y), _p(x), dtype_code(x.dtype), pix_stride(x), Cc, _p(dwp), int(dwp.shape[2]),
+         N, H, W, float(out_scale), _p(out_scale_n), stream_ptr())
+    return dwp
+
+
 # ---------------------------------------------------------------------------------------------
 # silog
 # ---------------------------------------------------------------------------------------------

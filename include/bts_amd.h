@@ -216,6 +216,11 @@ int bts_conv3x3_c1_fwd(const void* x, int dtype, int x_stride, int C, const floa
 int bts_conv3x3_c1_dgrad(const float* grad_y, const float* y, const float* w, void* grad_x, int dtype, int grad_x_stride,
                          int C, int accumulate, const void* fold_elu_y, int fold_elu_stride, int N, int H, int W,
                          float out_scale, const float* out_scale_n, bts_stream_t stream);
+/* Weight gradient of the same layer, ACCUMULATED (atomic adds: zero dw first) into the packed layout of bts_conv_wgrad for one
+ * output channel:  dw[t * dw_ktot + c] += sum_{n,q} x[n][q][c] * dz[n][q - t]  (dz as above, formed from grad_y and y in the
+ * kernel: no dz map is read or written).  x is read exactly once. */
+int bts_conv3x3_c1_wgrad(const float* grad_y, const float* y, const void* x, int dtype, int x_stride, int C, float* dw,
+                         int dw_ktot, int N, int H, int W, float out_scale, const float* out_scale_n, bts_stream_t stream);
 
 /* Weight gradient of the convolution described by `d` (d->w, d->y unused):
  *   dw[co][p*T+t][k] += sum_pixels dz[out pixel][co] * x_t[in pixel][k]

@@ -244,6 +244,15 @@ def test_conv3x3_c1_streaming_kernels(dt, shape):
     gf = torch.empty_like(xd)
     ops.conv3x3_c1_dgrad(gyd, y, wd, gf, False, 80.0, None, yelu)       # no per-image scale: y was produced with one, so only shape-check
     assert torch.isfinite(gf.float()).all()
+    # weight gradient into the packed [1][9][Ktot] layout (accumulating: starts from a known base), Ktot wider than C
+    wq_r = wq.clone().requires_grad_(True)
+    (torch.sigmoid(F.conv2d(x, wq_r, padding=1)) * 80.0 * sc_n.view(-1, 1, 1, 1)).backward(gy)
+    ktot = Cc + v
+    dwp = torch.full((1, 9, ktot), 0.5, device=DEV)
+    ops.conv3x3_c1_wgrad(gyd, y, xd, dwp, 80.0, scd)
+    got = (dwp[0, :, :Cc] - 0.5).t().reshape(Cc, 3, 3).cpu()            # [t][c] -> [c][ky][kx]
+    assert rel(got, wq_r.grad[0]) < (2e-4 if dt == torch.float32 else 5e-3)
+    assert (dwp[0, :, Cc:] == 0.5).all()                                # the padding columns are not touched
 
 
 def test_conv_epilogues():

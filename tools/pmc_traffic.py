@@ -42,6 +42,8 @@ def family(name):
         return "conv_c1_fwd"
     if n.startswith("conv_c1_dgrad"):
         return "conv_c1_dgrad"
+    if n.startswith("conv_c1_wgrad"):
+        return "conv_c1_wgrad"
     if n.startswith("conv_wgrad_c1"):
         return "conv_wgrad_c1<bf16>"
     if n.startswith("bn_bwd_"):

@@ -391,6 +391,151 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_tn_ring_ra2(const GemmP a) {
     }
 }
 
+
+// ---- wave specialisation: NP producer waves only generate addresses and issue LDS-DMA, WR x WC consumer waves only read fragments
+// and multiply.  Hypothesis (round 3, section 9c of DESIGN.md): the LDS-DMA issue cost (60-185 cycles per instruction in a wave that
+// also carries MFMAs) is what keeps the all-waves-do-everything structure at ~0.3-0.38 of the peak.  One s_barrier per chunk for
+// everybody: B_c publishes stage c (every producer waited for its own pieces of it) and frees stage c-1 (every consumer's reads of it
+// returned before its last k-step), behind it the producers refill stage c-1 with chunk c+NST-1 and the consumers work on stage c.
+template <int WR, int WC, int NP, int NST, int ABL>
+__global__ __launch_bounds__((WR* WC + NP) * 64) void gemm_tn_pc(const GemmP a) {
+    constexpr int FA = 2, FB = 2, KC = 64, NCW = WR * WC;
+    constexpr int TM = WR * FA * 32, TN = WC * FB * 32;
+    constexpr int NSA = TM / 64, NSB = TN / 64, NSUB = NSA + NSB;
+    constexpr int SUB = KC * 128, ROWS = NSUB * KC, NI = ROWS / 8, GP = NI / NP, STAGE = NSUB * SUB;
+    constexpr int KS = 4, NM = 4, R = 8;
+    static_assert(NI % NP == 0 && NST >= 3 && (NST - 2) * GP <= 63, "shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.y;
+    const int L = remap_xcd(blockIdx.x, a.n_m_tiles * a.n_n_tiles);
+    const int mt = L % a.n_m_tiles, nt = L / a.n_m_tiles;
+    const int c_begin = split * a.chunks_per_split;
+    const int c_end = min(a.nchunks, c_begin + a.chunks_per_split);
+    if (wave >= NCW) {
+        // ------------------------------------------------ producer ------------------------------------------------
+        const int pw = wave - NCW;
+        const char* zero = (const char*)kZeroPage;
+        const int pc = lane & 7, r8 = lane >> 3;
+        const int lp = pc ^ (((r8 >> 1) & 1) << 2);
+        const char* cbase[GP];
+        int krow[GP], ldk[GP];
+#pragma unroll
+        for (int g = 0; g < GP; ++g) {
+            const int d = pw + g * NP;                                   // stage rows 8d .. 8d+7
+            const int q = (d * 8) / KC;
+            krow[g] = (d * 8) % KC + r8;
+            if (q < NSA) { const int c = mt * TM + q * 64 + lp * 8; cbase[g] = c < a.M ? (const char*)(a.A + c) : nullptr; ldk[g] = a.lda; }
+            else { const int c = nt * TN + (q - NSA) * 64 + lp * 8; cbase[g] = c < a.N ? (const char*)(a.B + c) : nullptr; ldk[g] = a.ldb; }
+        }
+        auto fill = [&](int chunk, char* stage) {
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {
+                const int m = chunk * KC + krow[g];
+                const bool on = chunk < c_end && m < a.K && cbase[g];
+                const char* src = on ? cbase[g] + (size_t)m * ldk[g] * 2 : zero;
+                if constexpr (ABL != 2)
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(stage + (pw + g * NP) * 8 * 128), 16, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < NST - 1; ++s) fill(c_begin + s, smem + s * STAGE);
+        int wb = NST - 1;
+        for (int chunk = c_begin; chunk < c_end; ++chunk) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * GP) : "memory");      // own pieces of stage `chunk` landed
+            __builtin_amdgcn_s_barrier();                                                 // B_chunk
+            fill(chunk + NST - 1, smem + wb * STAGE);                                     // refills the stage of chunk-1
+            wb = wb + 1 == NST ? 0 : wb + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    // ---------------------------------------------------- consumers ----------------------------------------------------
+    const int wr = wave / WC, wc = wave % WC;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int key = i16 >> 2, cg = i16 & 3, kb = g4 >> 1, chh = g4 & 1;
+    const int sw = (key >> 1) & 1;
+    uint32_t fo[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int c32 = f < FA ? wr * FA + f : wc * FB + (f - FA);
+        const int sub = (f < FA ? 0 : NSA) + (c32 >> 1), half = c32 & 1;
+        fo[f] = sub * SUB + (kb * 8 + key) * 128 + ((half ^ sw) << 6) + chh * 32 + cg * 8;
+    }
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const uint32_t s0 = lds_addr(smem);
+    Frag fr[2][4];
+    auto rd = [&](auto setc, auto sc, auto rc, uint32_t sT) {
+        constexpr int set = decltype(setc)::value, S = decltype(sc)::value, r = decltype(rc)::value, f = r >> 1;
+        if constexpr (ABL != 1) {
+            if constexpr (r & 1) tr_issue<S * 16 * 128 + 512>(fr[set][f].hi, sT + fo[f]);
+            else tr_issue<S * 16 * 128>(fr[set][f].lo, sT + fo[f]);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    int rb = 0;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        __builtin_amdgcn_s_barrier();                                                     // B_chunk
+        const uint32_t sT = s0 + rb * STAGE;
+        static_for<R>([&](auto rc) { rd(I0{}, I0{}, rc, sT); });
+        static_for<KS>([&](auto sc) {
+            constexpr int S = decltype(sc)::value, CUR = S & 1, NXT = CUR ^ 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            static_for<NM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value, i = m / FB, j = m % FB;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ABL != 1) Mma<BF16>::run(frag_vec(fr[CUR][i]), frag_vec(fr[CUR][FA + j]), acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (S + 1 < KS) {
+                    constexpr int r_lo = m * R / NM, r_hi = (m + 1) * R / NM;
+                    static_for<r_hi - r_lo>([&](auto k) {
+                        rd(std::integral_constant<int, NXT>{}, std::integral_constant<int, S + 1>{},
+                           std::integral_constant<int, r_lo + decltype(k)::value>{}, sT);
+                    });
+                }
+            });
+        });
+        rb = rb + 1 == NST ? 0 : rb + 1;
+    }
+    const int frow = lane & 31, fk = lane >> 5;
+    const bool single = gridDim.y == 1;
+#pragma unroll
+    for (int j = 0; j < FB; ++j) {
+        const int col = nt * TN + (wc * FB + j) * 32 + frow;
+        const bool col_ok = col < a.N;
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+            const int rbk = mt * TM + (wr * FA + i) * 32;
+            const int row0 = rbk + 4 * fk;
+            float* p0 = a.C + (size_t)row0 * a.ldc + (col_ok ? col : 0);
+            if (single && rbk + 32 <= a.M) {
+                if (col_ok) {
+                    float old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) old[r] = p0[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldc];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p0[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldc] = old[r] + acc[i][j][r];
+                }
+            } else if (col_ok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (row0 + dr >= a.M) continue;
+                    if (single) p0[(size_t)dr * a.ldc] += acc[i][j][r];
+                    else atomicAdd(p0 + (size_t)dr * a.ldc, acc[i][j][r]);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 static float h_bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
 static uint16_t h_f2bf(float f) {
@@ -445,6 +590,24 @@ static void launch_ra2(GemmP p, int splits, hipStream_t st) {
     hipLaunchKernelGGL((gemm_tn_ring_ra2<WR, WC, NST, ABL>), dim3(p.n_m_tiles * p.n_n_tiles, splits), dim3(WR * WC * 64), LDS, st, p);
 }
 
+template <int WR, int WC, int NP, int NST, int ABL>
+static void launch_pc(GemmP p, int splits, hipStream_t st) {
+    constexpr int KC = 64, TM = WR * 64, TN = WC * 64, LDS = NST * (TM + TN) / 64 * KC * 128;
+    static_assert(LDS <= 160 * 1024, "LDS");
+    static bool attr = false;
+    if (!attr) {
+        HIPCHECK(hipFuncSetAttribute((const void*)gemm_tn_pc<WR, WC, NP, NST, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    p.n_m_tiles = (p.M + TM - 1) / TM;
+    p.n_n_tiles = (p.N + TN - 1) / TN;
+    p.nchunks = (p.K + KC - 1) / KC;
+    if (splits > p.nchunks) splits = p.nchunks;
+    p.chunks_per_split = (p.nchunks + splits - 1) / splits;
+    splits = (p.nchunks + p.chunks_per_split - 1) / p.chunks_per_split;
+    hipLaunchKernelGGL((gemm_tn_pc<WR, WC, NP, NST, ABL>), dim3(p.n_m_tiles * p.n_n_tiles, splits), dim3((WR * WC + NP) * 64), LDS, st, p);
+}
+
 struct Variant { const char* name; void (*fn)(GemmP, int, hipStream_t); int tm, tn, lds_kib; bool checked; };
 #define V_(WR, WC, FA, FB, KC, NST, PF, ABL) \
     {#WR "x" #WC " f" #FA "x" #FB " KC" #KC " NST" #NST " PF" #PF " ABL" #ABL, launch<WR, WC, FA, FB, KC, NST, PF, ABL>, WR * FA * 32, WC * FB * 32, \
@@ -467,6 +630,13 @@ static const Variant variants[] = {
     V_(4, 2, 2, 4, 32, 4, 1, 0),      // 256x256, wave = 64 x 128
     V_(2, 4, 4, 2, 32, 4, 1, 1),      // ablations of the 256x256 ring: staging only / MFMA + reads only
     V_(2, 4, 4, 2, 32, 4, 1, 2),
+    // wave specialisation: 8 consumer waves (128 x 256) + NP producer waves
+    {"PC 2x4 + 4 producers NST3", launch_pc<2, 4, 4, 3, 0>, 128, 256, 144, true},
+    {"PC 2x4 + 2 producers NST3", launch_pc<2, 4, 2, 3, 0>, 128, 256, 144, true},
+    {"PC 2x4 + 8 producers NST3", launch_pc<2, 4, 8, 3, 0>, 128, 256, 144, true},
+    {"PC 2x2 + 2 producers NST3 (96 KiB)", launch_pc<2, 2, 2, 3, 0>, 128, 128, 96, true},
+    {"PC 2x4 + 4 producers NST3 ABL1", launch_pc<2, 4, 4, 3, 1>, 128, 256, 144, false},
+    {"PC 2x4 + 4 producers NST3 ABL2", launch_pc<2, 4, 4, 3, 2>, 128, 256, 144, false},
     // occupancy: the transposing 8-byte reads reach the LDS rate only from ~4 waves per SIMD (MI355X_MICROARCH.md, LDS): small
     // stages + <= 128 VGPRs put 3-4 four-wave workgroups on a CU instead of 2
     {"OCC4 2x2 f2x2 KC32 NST2 PF0", launch<2, 2, 2, 2, 32, 2, 0, 0, 4>, 128, 128, 32, true},
@@ -522,8 +692,10 @@ static void check(const Variant& v, int M, int N, int K, int splits) {
 int main(int argc, char** argv) {
     const bool check_only = argc > 1 && !strcmp(argv[1], "--check-only");
     HIPCHECK(hipSetDevice(0));
+    const char* filter = getenv("PROBE_FILTER");                 // substring of the variant name; unset = all variants
+    auto wanted = [&](const Variant& v) { return !filter || strstr(v.name, filter); };
     for (const Variant& v : variants) {
-        if (!v.checked) continue;
+        if (!v.checked || !wanted(v)) continue;
         check(v, 320, 200, 200, 1);        // partial second tile on both sides, ragged last chunk
         check(v, 256, 512, 448, 3);        // several chunks per split, 3-way split with atomics
         check(v, 72, 40, 64, 1);           // smaller than one tile
@@ -549,6 +721,7 @@ int main(int argc, char** argv) {
     HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
     for (const Shape& s : shapes)
         for (const Variant& v : variants) {
+            if (!wanted(v)) continue;
             const int tiles = ((s.M + v.tm - 1) / v.tm) * ((s.N + v.tn - 1) / v.tn);
             const int per_cu = v.lds_kib <= 32 ? 4 : v.lds_kib <= 48 ? 3 : v.lds_kib <= 80 ? 2 : 1;
             // candidate pixel splits: fill one round of the chip, and twice that
