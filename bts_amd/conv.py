@@ -73,11 +73,12 @@ def _wide_pays(cout, n, hg, wg):
         return False
     if mode == "2":
         return True
+    bm = 128 if cout > 64 else 64
     ntiles = _cdiv(wg, 32) * _cdiv(hg, 8) * n
-    nco = _cdiv(cout, 128)
+    nco = _cdiv(cout, bm)
     wgs = ntiles * nco
     rounds = _cdiv(wgs, cus)
-    fill = (hg * wg * n / (ntiles * 256.0)) * (cout / (nco * 128.0)) * (wgs / float(rounds * cus))
+    fill = (hg * wg * n / (ntiles * 256.0)) * (cout / float(nco * bm)) * (wgs / float(rounds * cus))
     return fill >= float(os.environ.get("BTS_WIDE_FILL", "0.60"))
 
 
@@ -86,6 +87,10 @@ _CONV_BIG_DEFAULT = "t"      # launch_fwd()'s default schedule letter (csrc/conv
 
 def _fwd_kernel(dtype, cout, halo, geom=None, kv=8, up=False):
     """Name of the kernel launch_fwd() (csrc/conv_igemm.hip) picks: profiler label = rocprofv3 kernel family."""
+    if (halo and not up and dtype == torch.bfloat16 and 32 < cout <= 64 and kv > 8 and geom is not None
+            and os.environ.get("BTS_CONV_WIDE64", "1")[:1] != "0" and os.environ.get("BTS_CONV_WIDE", "1")[:1] != "0"
+            and _wide_pays(cout, *geom)):
+        return "conv_halo_wide<bf16,64x256>"
     if halo and cout <= 64:
         return "conv_halo<%s>" % _dn(dtype)
     if halo and not up and dtype == torch.bfloat16 and kv >= 8 and geom is not None and _wide_pays(cout, *geom):
@@ -102,6 +107,10 @@ def _wgrad_kernel(dtype, cout, radius1, up, n, hg, wg, cols=None):
     """Mirrors launch_wgrad() / launch_wgrad_tr().  cols = taps per phase x padded input channels (T * Ktot)."""
     if radius1 and not up and cout == 1:
         return "conv_wgrad_c1<%s>" % _dn(dtype)
+    if (radius1 and not up and 1 < cout <= int(os.environ.get("BTS_WGRAD_HALO_TR_MAXCOUT", "128")) and dtype == torch.bfloat16
+            and _cdiv(wg, 32) * _cdiv(hg, 8) * n >= int(os.environ.get("BTS_WGRAD_HALO_TR_MINTILES", "256"))
+            and os.environ.get("BTS_WGRAD_HALO_TR", "1")[:1] != "0"):
+        return "conv_wgrad_halo_tr<bf16>"
     if 32 < cout <= 64 and dtype == torch.bfloat16 and os.environ.get("BTS_WGRAD_RING64", "1") != "0":
         return "conv_wgrad_ring<bf16,64x256>"
     if radius1 and cout <= 64 and dtype == torch.bfloat16 and _cdiv(wg, 32) * _cdiv(hg, 8) * n >= 256:

@@ -34,16 +34,23 @@ constexpr int TH = 8, TW = 32, PW = TW + 2, PR = (TH + 2) * PW;      // tile, pa
 constexpr int NTHR = 64 * TH, RP = NTHR / 8;                          // 512 threads, 64 rows per DMA pass
 constexpr int PR_PAD = (PR + RP - 1) / RP * RP;                       // 384
 constexpr int NPASS = PR_PAD / RP;                                    // 6 patch pieces per thread
-constexpr int NCO = 4, BM = NCO * 32;                                 // 128 output channels per workgroup
-constexpr int WPASS = BM / RP;                                        // 2 weight pieces per thread per tap
-constexpr int NWS = 4;                                                // weight ring stages (2 x 48 KiB + 4 x 16 KiB = all 160 KiB of LDS)
-constexpr int PBYTES = PR_PAD * 128, WBYTES = BM * 128;
-constexpr int LDS_BYTES = 2 * PBYTES + NWS * WBYTES;                  // 2 x 49152 + 4 x 16384 = 163840
-static_assert(LDS_BYTES <= 160 * 1024, "conv_halo_wide: patch double buffer + weight ring exceed the 160 KiB of a CU");
+constexpr int NWS = 4;                                                // weight ring stages
+constexpr int PBYTES = PR_PAD * 128;
+// NCO = 32-channel output tiles per workgroup: 4 (128 co, the layers with > 64 output channels: 2 x 48 KiB + 4 x 16 KiB = all 160 KiB
+// of LDS) or 2 (64 co, r3: conv2 forward -- 161 -> 64 channels at half resolution, until then on the unpipelined conv_halo with its
+// patch staged once per 32-channel tile; 2 x 48 + 4 x 8 = 128 KiB)
+template <int NCO>
+constexpr int wide_lds_bytes() { return 2 * PBYTES + NWS * NCO * 32 * 128; }
+static_assert(wide_lds_bytes<4>() <= 160 * 1024, "conv_halo_wide: patch double buffer + weight ring exceed the 160 KiB of a CU");
 
+template <int NCO>
 __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
     using T = BF16;
     constexpr int VEC = T::kVec, ES = T::kBytes;
+    constexpr int BM = NCO * 32;                                       // output channels per workgroup
+    constexpr int WPASS = BM / RP;                                     // weight pieces per thread per tap (2 / 1)
+    constexpr int WBYTES = BM * 128;
+    static_assert(BM % RP == 0, "whole DMA passes per tap");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sPatch = smem;
     char* sWring = smem + 2 * PBYTES;
@@ -218,10 +225,10 @@ __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
             const uint32_t pb1 = tap == 8 ? pnext : pbase;
             // ---- first half: MFMAs of k-steps 0,1 (set A, read half a step ago); the reads of k-steps 2,3 sit in their shadows
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            static_for(std::make_integer_sequence<int, 8>{}, [&](auto m_c) {
+            static_for(std::make_integer_sequence<int, 2 * NCO>{}, [&](auto m_c) {
                 constexpr int m = decltype(m_c)::value;
                 mfma_one(m_c, fbA, faA);
-                if constexpr (m < 5) {
+                if constexpr (m < NCO + 1) {                           // the 2 (NCO + 1) reads of the half step, two per MFMA shadow
                     read_one(tap_c, H1{}, std::integral_constant<int, 2 * m>{}, fbB, faB, pbase, st);
                     read_one(tap_c, H1{}, std::integral_constant<int, 2 * m + 1>{}, fbB, faB, pbase, st);
                 }
@@ -237,15 +244,17 @@ __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
             __builtin_amdgcn_s_barrier();
             // ---- second half: MFMAs of k-steps 2,3 (set B); prefetch of the next step's set A first, then the DMA issue
             if constexpr (tap == 0) next_patch_seg(chunk + 1);
-            static_for(std::make_integer_sequence<int, 8>{}, [&](auto m_c) {
+            static_for(std::make_integer_sequence<int, 2 * NCO>{}, [&](auto m_c) {
                 constexpr int m = decltype(m_c)::value;
                 mfma_one(m_c, fbB, faB);
-                if constexpr (m < 5) {
+                if constexpr (m < NCO + 1) {
                     read_one(TN{}, H0{}, std::integral_constant<int, 2 * m>{}, fbA, faA, pb1, st1);
                     read_one(TN{}, H0{}, std::integral_constant<int, 2 * m + 1>{}, fbA, faA, pb1, st1);
-                } else if constexpr (m == 5) {
-                    fire_weights(j + NWS, st);
-                } else if constexpr (m == 6) {
+                }
+                // DMA issue behind the reads: the step's weights first, then its patch piece (the order the vmcnt arithmetic assumes);
+                // with NCO = 2 both land in the last MFMA shadow
+                if constexpr (m == NCO + 1) fire_weights(j + NWS, st);
+                if constexpr (m == (NCO + 2 < 2 * NCO ? NCO + 2 : 2 * NCO - 1)) {
                     if constexpr (tap < NPASS) fire_patch_piece((chunk + 1) & 1, tap_c);
                 }
             });
@@ -278,14 +287,13 @@ __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
 
 }  // namespace
 
-int launch_halo_wide(const ConvK& k0, hipStream_t st, int force) {
-    ConvK k = k0;
-    if (!(k.halo_ok && k.nphase == 1 && k.T == 9 && k.osc == 1 && k.Cout > 64)) return BTS_ERR_UNSUPPORTED;
-    if (!segs_fit_u32(k)) return BTS_ERR_UNSUPPORTED;                  // ppix * sb is a 32-bit product in the kernel
+template <int NCO>
+static int launch_halo_wide_n(ConvK& k, hipStream_t st, int force) {
+    constexpr int BM = NCO * 32, LDS_BYTES = wide_lds_bytes<NCO>();
     k.n_co_tiles = ceil_div(k.Cout, BM);
     const int ntiles = ceil_div(k.Wg, TW) * ceil_div(k.Hg, TH) * k.N;
     if (!force) {
-        // One 144 KiB workgroup per CU: the kernel only pays where its tiles cover the map, its co tiles are full and its
+        // One 128-144 KiB workgroup per CU: the kernel only pays where its tiles cover the map, its co tiles are full and its
         // workgroups fill whole rounds of the 256 CUs.  Measured (r02m, same box, vs conv_igemm_dma): conv4 +21 %, conv3 +25 %,
         // daspp_conv +16 % at a combined fill of 0.82; conv5 (22x76 map: 72 % tile cover, 288 workgroups = 2 rounds) -33 % at 0.40.
         const long wgs = (long)ntiles * k.n_co_tiles, cus = bts_cu_count();
@@ -299,10 +307,17 @@ int launch_halo_wide(const ConvK& k0, hipStream_t st, int force) {
         if (fill < min_fill) return BTS_ERR_UNSUPPORTED;
     }
     static DynLdsCache lds_set;
-    if (ensure_dyn_lds((const void*)conv_halo_wide, LDS_BYTES, lds_set) != BTS_OK) return BTS_ERR_LAUNCH;
-    hipLaunchKernelGGL(conv_halo_wide, dim3((unsigned)(ntiles * k.n_co_tiles)), dim3(NTHR), (size_t)LDS_BYTES, st, k);
+    if (ensure_dyn_lds((const void*)conv_halo_wide<NCO>, LDS_BYTES, lds_set) != BTS_OK) return BTS_ERR_LAUNCH;
+    hipLaunchKernelGGL(conv_halo_wide<NCO>, dim3((unsigned)(ntiles * k.n_co_tiles)), dim3(NTHR), (size_t)LDS_BYTES, st, k);
     if (hipGetLastError() != hipSuccess) return BTS_ERR_LAUNCH;
     return BTS_OK;
+}
+
+int launch_halo_wide(const ConvK& k0, hipStream_t st, int force) {
+    ConvK k = k0;
+    if (!(k.halo_ok && k.nphase == 1 && k.T == 9 && k.osc == 1 && k.Cout > 32)) return BTS_ERR_UNSUPPORTED;
+    if (!segs_fit_u32(k)) return BTS_ERR_UNSUPPORTED;                  // ppix * sb is a 32-bit product in the kernel
+    return k.Cout > 64 ? launch_halo_wide_n<4>(k, st, force) : launch_halo_wide_n<2>(k, st, force);
 }
 
 }  // namespace bts_conv

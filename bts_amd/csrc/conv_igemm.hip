@@ -1897,6 +1897,16 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
     auto go = [&](auto kern, int BM, int BN) { go2(kern, BM, BN, 256); };
     // narrow radius-1 layers: 2-D tile with LDS halo (see conv_halo)
     static const int halo_on = [] { const char* e = getenv("BTS_CONV_HALO"); return (e && e[0] == '0') ? 0 : 1; }();
+    // 33..64 output channels over several channel chunks (conv2: 161 -> 64): the pipelined 64-co form of conv_halo_wide
+    // (BTS_CONV_WIDE64=0: A/B against conv_halo; BTS_CONV_WIDE=0 switches both wide forms off)
+    static const int wide64_on = [] {
+        const char* e = getenv("BTS_CONV_WIDE64"); const char* w = getenv("BTS_CONV_WIDE");
+        return ((e && e[0] == '0') || (w && w[0] == '0')) ? 0 : 1;
+    }();
+    if (wide64_on && use_lds_dma() && T::kBytes == 2 && k.halo_ok && k.Cout > 32 && k.Cout <= 64 && k.nphase == 1 && k.T == 9 && k.KV > 8) {
+        const int rc = launch_halo_wide(k, st, 0);
+        if (rc != BTS_ERR_UNSUPPORTED) return rc;
+    }
     if (halo_on && use_lds_dma() && k.halo_ok && k.Cout <= 64) {
         const int co_tiles = ceil_div(k.Cout, 32);
         const bool one_chunk = k.KV <= 8;       // whole K in one 128-byte channel chunk: persistent variant
@@ -2032,6 +2042,18 @@ static int launch_wgrad(const ConvK& k0, hipStream_t st) {
         hipLaunchKernelGGL(conv_wgrad_c1<T>, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, k, kvp_log2);
         BTS_LAUNCH_CHECK();
         return BTS_OK;
+    }
+    // radius-1 3x3 layers with <= 128 output channels on large maps (conv1, conv2, conv3): LDS-halo tile + transposing reads
+    // (conv_wgrad_tr.hip).  Same box, gpurun r03ag/r03ah: conv2 375 -> 220 us (64 x 256 ring form), conv1 258 -> 172 (scatter
+    // kernel), conv3 194 -> 166 (128 x 256 ring, two 64-channel output tiles); conv4 / daspp_conv (240 tiles of 8 x 32, 4 / 2 output
+    // tiles) 147 -> 153: they keep the ring form.  BTS_WGRAD_HALO_TR=0, .._MAXCOUT, .._MINTILES: A/B.
+    static const int halo_tr_on = [] { const char* e = getenv("BTS_WGRAD_HALO_TR"); return (e && e[0] == '0') ? 0 : 1; }();
+    static const int halo_tr_mintiles = [] { const char* e = getenv("BTS_WGRAD_HALO_TR_MINTILES"); return e ? atoi(e) : 256; }();
+    static const int halo_tr_maxco = [] { const char* e = getenv("BTS_WGRAD_HALO_TR_MAXCOUT"); return e ? atoi(e) : 128; }();
+    if (halo_tr_on && T::kBytes == 2 && k.halo_ok && k.nphase == 1 && k.T == 9 && k.Cout > 1 && k.Cout <= halo_tr_maxco &&
+        ceil_div(k.Wg, 32) * ceil_div(k.Hg, 8) * k.N >= halo_tr_mintiles) {
+        const int rc = launch_wgrad_halo_tr(k, st);
+        if (rc != BTS_ERR_UNSUPPORTED) return rc;
     }
     // 64-output-channel layers (conv2, upconv2, and every other 33..64-channel bf16 layer): 64 x 256 ring form of the transposing
     // kernel.  Measured against the LDS-halo kernels (gpurun r03k): conv2 481 -> 368 us, upconv2 168 -> 123 us.  BTS_WGRAD_RING64=0: A/B.

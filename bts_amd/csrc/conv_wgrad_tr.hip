@@ -441,11 +441,191 @@ __global__ __launch_bounds__(WR* WC * 64) void conv_wgrad_ring(const ConvK a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the narrow radius-1 3x3 layers (conv1, conv2: Cout <= 64) on a 2-D pixel tile with an LDS halo, transposing
+// reads instead of a transposing scatter (r3).
+//
+// conv_wgrad_halo (conv_igemm.hip) transposes the patch with eight ds_write_b16 per loaded vector and runs load -> scatter ->
+// barrier -> MFMA in sequence (conv1: 273 TF); the 64 x 256 ring form of the kernel above re-stages the input once per tap and has
+// 51 FLOP per staged byte (conv2: 410-425 TF, the LDS-DMA fill rate).  Here the (8+2) x 34 input patch of one 64-channel chunk and
+// the 8 x 32 dz tile go to LDS once per tile, as they lie in memory (rows = pixels, 128 B = 64 channels, LDS-DMA, same half-swap on
+// the source side as above), and EVERY tap reads its x fragments from the same patch at a shifted ROW: a tap is a row offset
+// (dy * 34 + dx), which ds_read_b64_tr_b16 takes like any other address.  337 FLOP per staged byte.
+//
+//   workgroup = 9 waves, wave = tap; it owns dW[co 0..32 NCH)[tap][64 channels of the chunk] = NCH x 2 accumulator tiles and walks
+//   a contiguous range of tiles (stage = 600 rows x 128 B = 75 KiB, two stages, one barrier per tile, the next tile's DMA in flight
+//   under the 16 k-steps of this one); one set of atomics per workgroup.  grid = (pixel-range workers, channel chunks).
+//
+// Half-swap phase of the shifted rows: row = cB + 34 ty + 16 h  =>  (row >> 1) & 1 = ((cB >> 1) + ty) & 1: the swap flips with the
+// tile row, so every fragment address is (per-lane base, one of two per-lane in-row offsets) + an immediate.
+template <int NCH>
+__global__ __launch_bounds__(576) void conv_wgrad_halo_tr(const ConvK a) {
+    constexpr int TH = 8, TW = 32, PW = TW + 2, PR = (TH + 2) * PW;       // 340 patch rows
+    constexpr int ZR0 = 344;                                               // first dz row: a multiple of 4 keeps its swap phase = key
+    constexpr int ROWS = ZR0 + TH * TW, STAGE = ROWS * 128;                // 600 rows, 76800 B
+    constexpr int NW = 9, RPP = NW * 8, NPASS = (ROWS + RPP - 1) / RPP;    // 72 rows per DMA pass; the ninth pass is partial (wave-uniform)
+    static_assert(ZR0 % 4 == 0 && ZR0 >= PR && RPP % 4 == 0, "swap phase of a DMA row must depend on the lane only");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = blockIdx.y;
+    const char* zero = (const char*)kZeroPage;
+    const int tiles_x = (a.Wg + TW - 1) / TW, tiles_y = (a.Hg + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * a.N;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
+    if (t_begin >= t_end) return;
+
+    // ---- DMA roles: piece pc of row r8 of the wave's 8-row group in every pass ----------------------------------------------------
+    const int pc = lane & 7, r8 = lane >> 3;
+    const int lp = pc ^ (((r8 >> 1) & 1) << 2);                            // logical 16-byte piece (half swap; row phase = r8 phase)
+    const int cv = chunk * 8 + lp;
+    const char* xbase = nullptr;
+    uint32_t xsb = 0;
+    if (cv < a.KV) {
+        int seg, seg_end; const char* sp; uint32_t coffB;
+        pick_seg_b(a, cv, 16, seg, sp, xsb, coffB, seg_end);
+        xbase = sp + coffB;
+    }
+    const int co0 = blockIdx.z * 64;                                       // 64-channel output tile (wider layers: the patch is re-staged per tile)
+    const char* zbase = co0 + lp * 8 < a.Cout ? a.dz + (co0 + lp * 8) * 2 : nullptr;
+    const uint32_t zsb = (uint32_t)a.dz_stride * 2u;
+    auto fire = [&](int tile, char* stage) {
+        const int tx = tile % tiles_x, r1 = tile / tiles_x;
+        const int y0 = (r1 % tiles_y) * TH, n = r1 / tiles_y, x0 = tx * TW;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int rowg = p * RPP + wave * 8;                           // wave-uniform
+            if (rowg < ROWS) {
+                const int row = rowg + r8;
+                const char* src = zero;
+                if (row < PR) {
+                    const int py = row / PW, px = row - py * PW;
+                    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+                    if (xbase && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx)
+                        src = xbase + (size_t)((uint32_t)((n * a.Hx + iy) * a.Wx + ix) * xsb);
+                } else if (row >= ZR0) {
+                    const int zr = row - ZR0;
+                    const int oy = y0 + (zr >> 5), ox = x0 + (zr & 31);
+                    if (zbase && oy < a.Hg && ox < a.Wg) src = zbase + (size_t)((uint32_t)((n * a.Hy + oy) * a.Wy + ox) * zsb);
+                }
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(stage + rowg * 128), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- fragment roles ---------------------------------------------------------------------------------------------------------
+    int dy, dx, ioy, iox;
+    decode_tap(a.taps[wave], dy, dx, ioy, iox);                            // a.T == 9 (launcher): wave = tap
+    const int i16 = lane & 15, g = lane >> 4;
+    const int key = tr_key(i16), cg = tr_cg(i16), kb = g >> 1, chh = g & 1;
+    const int inrow = chh * 32 + cg * 8;
+    const int swA = (key >> 1) & 1;
+    const int cB = (1 + dy) * PW + 1 + dx + kb * 8 + key;
+    const int swB0 = (cB >> 1) & 1;
+    const uint32_t lds0 = lds_addr(smem);
+    uint32_t aA[NCH], bB[2][2];                                            // byte offsets inside a stage
+#pragma unroll
+    for (int ca = 0; ca < NCH; ++ca) aA[ca] = (uint32_t)((ZR0 + kb * 8 + key) * 128 + ((ca ^ swA) << 6) + inrow);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int par = 0; par < 2; ++par) bB[cb][par] = (uint32_t)(cB * 128 + ((cb ^ swB0 ^ par) << 6) + inrow);
+
+    f32x16_t acc[NCH][2];
+#pragma unroll
+    for (int ca = 0; ca < NCH; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ca][cb][r] = 0.f;
+
+    Frag fa[2][NCH], fb[2][2];
+    // the NCH + 2 fragments of k-step S (tile row S >> 1, half S & 1) into register set SET; R = 0 .. NCH + 1 selects one of them
+    auto read_frag = [&](auto s_c, auto set_c, auto r_c, uint32_t sbase) {
+        constexpr int S = decltype(s_c)::value, SET = decltype(set_c)::value, R = decltype(r_c)::value;
+        constexpr int ty = S >> 1, h = S & 1;
+        if constexpr (R < NCH) {
+            tr_issue<S * 16 * 128>(fa[SET][R].lo, sbase + aA[R]);
+            tr_issue<S * 16 * 128 + 512>(fa[SET][R].hi, sbase + aA[R]);
+        } else {
+            constexpr int cb = R - NCH, OFF = (ty * PW + h * 16) * 128;
+            tr_issue<OFF>(fb[SET][cb].lo, sbase + bB[cb][ty & 1]);
+            tr_issue<OFF + 512>(fb[SET][cb].hi, sbase + bB[cb][ty & 1]);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    fire(t_begin, smem);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int cur = (tile - t_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's pieces of the tile have landed
+        __builtin_amdgcn_s_barrier();                                      // ... everybody's; and the other stage is no longer read
+        if (tile + 1 < t_end) fire(tile + 1, smem + (cur ^ 1) * STAGE);    // in flight under the 16 k-steps below
+        const uint32_t sbase = lds0 + cur * STAGE;
+        static_for_n<NCH + 2>([&](auto r_c) { read_frag(I0{}, I0{}, r_c, sbase); });
+        static_for_n<16>([&](auto s_c) {
+            constexpr int S = decltype(s_c)::value, CUR = S & 1, NXT = CUR ^ 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the fragments of k-step S have returned
+            static_for_n<NCH * 2>([&](auto m_c) {
+                constexpr int m = decltype(m_c)::value, ca = m >> 1, cb = m & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                Mma<BF16>::run(frag_vec(fa[CUR][ca]), frag_vec(fb[CUR][cb]), acc[ca][cb]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (S + 1 < 16) {
+                    // NCH + 2 fragments of the next k-step over the NCH * 2 MFMA shadows of this one
+                    constexpr int lo = m * (NCH + 2) / (NCH * 2), hi = (m + 1) * (NCH + 2) / (NCH * 2);
+                    static_for_n<hi - lo>([&](auto q_c) {
+                        read_frag(std::integral_constant<int, S + 1>{}, std::integral_constant<int, NXT>{},
+                                  std::integral_constant<int, lo + decltype(q_c)::value>{}, sbase);
+                    });
+                }
+            });
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: one set of atomics per workgroup (rows = co, lanes = consecutive channels: 128-byte runs) -------------------------
+    const int frow = lane & 31, fk = lane >> 5;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int k = chunk * 64 + cb * 32 + frow;
+        if (k >= a.Ktot) continue;
+#pragma unroll
+        for (int ca = 0; ca < NCH; ++ca)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + ca * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * a.Ttot + wave) * a.Ktot + k, acc[ca][cb][r]);
+            }
+    }
+}
+
 }  // namespace
 
 // 64 co x 256 columns, four waves, two stages (80 KiB: two workgroups per CU): the narrow full-resolution layers (conv2, upconv2:
 // 64 output channels).  Their LDS-halo kernels (conv_wgrad_halo*) transpose through 2-byte LDS scatters and re-stage X per
 // output-channel group (PMC, round 2: 1.1 GB fetched for 0.4 GB); here X is staged once per 256 columns as it lies.
+int launch_wgrad_halo_tr(const ConvK& k0, hipStream_t st) {
+    ConvK k = k0;
+    if (!(k.halo_ok && k.nphase == 1 && k.T == 9 && k.osc == 1 && k.Cout > 1)) return BTS_ERR_UNSUPPORTED;
+    if (!segs_fit_u32(k)) return BTS_ERR_UNSUPPORTED;
+    if ((unsigned long long)k.N * k.Hy * k.Wy * k.dz_stride * 2ull >= (1ull << 32)) return BTS_ERR_UNSUPPORTED;
+    const int ntiles = ceil_div(k.Wg, 32) * ceil_div(k.Hg, 8) * k.N;
+    const int nch = ceil_div(k.KV, 8), ncot = ceil_div(k.Cout, 64);
+    // one 150 KiB workgroup per CU: as many pixel-range workers per (channel chunk, co tile) as fill the chip once
+    int workers = bts_cu_count() / (nch * ncot);
+    if (workers < 1) workers = 1;
+    if (workers > ntiles) workers = ntiles;
+    constexpr int LDS = 2 * 600 * 128;
+    static DynLdsCache lds_set[2];
+    auto kern = k.Cout > 32 ? conv_wgrad_halo_tr<2> : conv_wgrad_halo_tr<1>;
+    if (ensure_dyn_lds((const void*)kern, LDS, lds_set[k.Cout > 32]) != BTS_OK) return BTS_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(workers, nch, ncot), dim3(576), (size_t)LDS, st, k);
+    if (hipGetLastError() != hipSuccess) return BTS_ERR_LAUNCH;
+    return BTS_OK;
+}
+
 int launch_wgrad_ring64(const ConvK& k0, hipStream_t st) {
     ConvK k = k0;
     if (k.Cout > 64 || k.Cout <= 32) return BTS_ERR_UNSUPPORTED;

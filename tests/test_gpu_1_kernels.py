@@ -115,6 +115,7 @@ CONV_CASES = [
     ("wg_halo_conv1like", 32, [32, 8], 9, 1, False, (8, 61, 125)),
     ("wg_halo_conv2like", 64, [64, 96, 8], 9, 1, False, (8, 61, 125)),
     ("wg_halo_1group", 24, [32], 9, 1, False, (8, 64, 128)),
+    ("wg_halo_wide_co", 136, [64, 40], 9, 1, False, (8, 61, 125)),  # > 64 output channels on a >= 256-tile map (3 ragged co tiles)
     ("wg_halo_up1like", 32, [64], 9, 1, True, (8, 61, 125)),      # conv_wgrad_halo_up, ragged
     ("wg_halo_up2like", 64, [128], 9, 1, True, (8, 64, 128)),     # 2 ci groups x 2 co groups
     ("wg_halo_up_small", 16, [24], 9, 1, True, (8, 64, 128)),     # one ci tile per role

@@ -99,11 +99,17 @@ def test_profiler_labels_follow_dispatch():
     assert conv._fwd_kernel(bf, 512, True, (8, 22, 76), 112) == "conv_igemm_dma<bf16,128x128>"
     assert conv._fwd_kernel(torch.float32, 256, True, (8, 44, 152), 112) == "conv_igemm_dma<f32,128x128>"
     assert conv._fwd_kernel(bf, 32, True) == "conv_halo<bf16>"
+    assert conv._fwd_kernel(bf, 64, True, (8, 176, 608), 21) == "conv_halo_wide<bf16,64x256>"      # conv2: 161 -> 64, three chunks
+    assert conv._fwd_kernel(bf, 64, True, (8, 176, 608), 8) == "conv_halo<bf16>"                   # one chunk: persistent conv_halo
+    assert conv._fwd_kernel(torch.float32, 64, True, (8, 176, 608), 41) == "conv_halo<f32>"
     assert conv._fwd_kernel(bf, 32, False) == "conv_igemm_dma<bf16,32x256>"
     assert conv._wgrad_kernel(bf, 1, True, False, 8, 352, 1216) == "conv_wgrad_c1<bf16>"
-    assert conv._wgrad_kernel(bf, 32, True, False, 8, 352, 1216) == "conv_wgrad_halo<bf16>"
+    assert conv._wgrad_kernel(bf, 32, True, False, 8, 352, 1216) == "conv_wgrad_halo_tr<bf16>"
     assert conv._wgrad_kernel(bf, 32, True, True, 8, 176, 608) == "conv_wgrad_halo_up<bf16>"
-    assert conv._wgrad_kernel(bf, 64, True, False, 8, 176, 608) == "conv_wgrad_ring<bf16,64x256>"      # conv2: 64-co ring form
+    assert conv._wgrad_kernel(bf, 64, True, False, 8, 176, 608) == "conv_wgrad_halo_tr<bf16>"          # conv2: LDS-halo tile + transposing reads
+    assert conv._wgrad_kernel(bf, 64, True, True, 8, 88, 304) == "conv_wgrad_ring<bf16,64x256>"        # upconv2: 64-co ring form
+    assert conv._wgrad_kernel(bf, 128, True, False, 8, 88, 304, 9 * 232) == "conv_wgrad_halo_tr<bf16>"   # conv3: two 64-channel output tiles
+    assert conv._wgrad_kernel(bf, 256, True, False, 8, 44, 152, 9 * 448) == "conv_wgrad_ring<bf16,128x256>"   # conv4: 240 tiles, stays
     assert conv._wgrad_kernel(f32, 32, True, False, 8, 352, 1216) == "conv_wgrad<f32,32x128k4>"
     assert conv._wgrad_kernel(bf, 32, True, False, 1, 32, 64) == "conv_wgrad<bf16,32x128k4>"      # < 256 tiles
     # wide bf16: LDS-DMA + transposing reads; 128 x 256 ring unless its tiles alone exceed two rounds of the chip (upconv5)

@@ -36,8 +36,13 @@ def family(name):
         return "conv_wgrad_ring<bf16,%dx%d>" % (int(m.group(1)) * 64, int(m.group(2)) * 64)
     if n.startswith("conv_wgrad_tr"):
         return "conv_wgrad_tr<bf16,128x128>"
+    m = re.match(r"conv_halo_wide<(\d)>", n)
+    if m:
+        return "conv_halo_wide<bf16,%dx256>" % (int(m.group(1)) * 32)
     if n.startswith("conv_halo_wide"):
         return "conv_halo_wide<bf16,128x256>"
+    if n.startswith("conv_wgrad_halo_tr"):
+        return "conv_wgrad_halo_tr<bf16>"
     if n.startswith("conv_c1_fwd"):
         return "conv_c1_fwd"
     if n.startswith("conv_c1_dgrad"):
