@@ -79,6 +79,15 @@ __device__ __forceinline__ float act_elu(float x) {
     const float p = x * (1.f + x * (0.5f + x * (0.16666667f + x * (0.041666668f + x * 0.0083333338f))));
     return x > -0.125f ? p : e;
 }
+// ELU for results that are ROUNDED TO BF16 when stored: elu(x) = max(x, exp(min(x, 0)) - 1) -- for x <= 0, e^x - 1 >= x, and for
+// x > 0 the right-hand side is 0 -- five VALU operations and no compare / select.  exp(x) - 1 loses relative (not absolute: ~6e-8)
+// accuracy for |x| < 1e-5, far below the 2^-9 of the bf16 store behind it; the f32 (parity) kernels keep act_elu.
+__device__ __forceinline__ float act_elu_bf16(float x) { return fmaxf(x, __expf(fminf(x, 0.f)) - 1.f); }
+template <typename T>
+__device__ __forceinline__ float act_elu_for(float x) {
+    if constexpr (T::kBytes == 2) return act_elu_bf16(x);
+    else return act_elu(x);
+}
 __device__ __forceinline__ float act_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
 // ---- wave / block reductions -----------------------------------------------

@@ -329,7 +329,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16_t (&acc)[TM
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float t = acc[i][j][r];
-                if (a.act == BTS_ACT_ELU) t = act_elu(t);
+                if (a.act == BTS_ACT_ELU) t = act_elu_for<T>(t);
                 else if (a.act == BTS_ACT_SIGMOID) t = act_sigmoid(t);
                 else if (a.act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
                 v[r] = t * sc;

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float t = acc[i][r];
-            if (a.act == BTS_ACT_ELU) t = act_elu(t);
+            if (a.act == BTS_ACT_ELU) t = act_elu_for<T>(t);
             else if (a.act == BTS_ACT_SIGMOID) t = act_sigmoid(t);
             else if (a.act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
             v[r] = t * sc;

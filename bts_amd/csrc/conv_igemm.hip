@@ -773,7 +773,7 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float t = acc[g][r];
-                if (a.act == BTS_ACT_ELU) t = act_elu(t);
+                if (a.act == BTS_ACT_ELU) t = act_elu_for<T>(t);
                 else if (a.act == BTS_ACT_SIGMOID) t = act_sigmoid(t);
                 else if (a.act == BTS_ACT_RELU) t = fmaxf(t, 0.f);
                 v[r] = t * sc;

@@ -78,10 +78,10 @@ __device__ __forceinline__ void activate_tile(const f32x16_t& acc, int tm, Act<B
         const int s = 2 * tm + h, q = 8 * h;
         if (s < KS) {
             u32x4_t v;
-            v.x = pack_bf16x2(act_elu(acc[q + 0]), act_elu(acc[q + 1]));
-            v.y = pack_bf16x2(act_elu(acc[q + 2]), act_elu(acc[q + 3]));
-            v.z = pack_bf16x2(act_elu(acc[q + 4]), act_elu(acc[q + 5]));
-            v.w = pack_bf16x2(act_elu(acc[q + 6]), act_elu(acc[q + 7]));
+            v.x = pack_bf16x2(act_elu_bf16(acc[q + 0]), act_elu_bf16(acc[q + 1]));
+            v.y = pack_bf16x2(act_elu_bf16(acc[q + 2]), act_elu_bf16(acc[q + 3]));
+            v.z = pack_bf16x2(act_elu_bf16(acc[q + 4]), act_elu_bf16(acc[q + 5]));
+            v.w = pack_bf16x2(act_elu_bf16(acc[q + 6]), act_elu_bf16(acc[q + 7]));
             out.v[s] = v;
         }
     }
@@ -306,6 +306,7 @@ struct ChainBwdK {
     void* dx;
     int dx_stride, dx_accumulate;
     int fold_elu;       // x is an ELU output and this launch completes its gradient: store (dx [+ old]) * ELU'(x)
+    int dx_wide;        // dx rows are 16-byte aligned: 32-channel blocks leave as 16-byte stores
     float* dw[6];       // per layer: packed f32 weight gradient [Cout][ld], accumulated atomically
     int dw_ld[6];
     long cells;
@@ -536,7 +537,50 @@ __global__ __launch_bounds__(256, (C0 >= 128 ? 1 : 2)) void lpg_chain_bwd_kernel
         if (t.ok) {                                        // dx: 4 consecutive channels per accumulator quad
             char* px = (char*)a.dx + ((size_t)t.cell * a.dx_stride) * 2;
 #pragma unroll
-            for (int tn = 0; tn < TN0; ++tn)
+            for (int tn = 0; tn < TN0; ++tn) {
+                if (a.dx_wide && 32 * tn + 32 <= C0) {
+                    // 16-byte form (as conv_common.h's store_block32): the two half-waves of a cell swap accumulator quads through
+                    // v_permlane32_swap so that a lane owns 8 consecutive channels twice -- two 16-byte stores (and loads of the old
+                    // value / the ELU output) per 32-channel block instead of four 8-byte ones
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = dA[tn][r];
+                    u32x4_t oldw[2], xw[2];
+#pragma unroll
+                    for (int p2 = 0; p2 < 2; ++p2) {
+                        const int ch = 32 * tn + 8 * (2 * p2 + g);
+                        if (a.dx_accumulate) oldw[p2] = *(const u32x4_t*)(px + ch * 2);
+                        if (a.fold_elu) xw[p2] = *(const u32x4_t*)((const char*)a.x + ((size_t)t.cell * a.x_stride + ch) * 2);
+                    }
+#pragma unroll
+                    for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 * p2 + e]), __float_as_uint(v[8 * p2 + 4 + e]), false, false);
+                            v[8 * p2 + e] = __uint_as_float(r[0]);
+                            v[8 * p2 + 4 + e] = __uint_as_float(r[1]);
+                        }
+#pragma unroll
+                    for (int p2 = 0; p2 < 2; ++p2) {
+                        float tv[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) tv[e] = v[8 * p2 + e];
+                        if (a.dx_accumulate) {
+                            float o[8];
+                            BF16::unpack(oldw[p2], o);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) tv[e] += o[e];
+                        }
+                        if (a.fold_elu) {
+                            float y[8];
+                            BF16::unpack(xw[p2], y);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) tv[e] *= elu_grad_from_out(y[e]);
+                        }
+                        *(u32x4_t*)(px + (32 * tn + 8 * (2 * p2 + g)) * 2) = BF16::pack(tv);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int ch = 32 * tn + 8 * q + 4 * g;
@@ -557,6 +601,7 @@ __global__ __launch_bounds__(256, (C0 >= 128 ? 1 : 2)) void lpg_chain_bwd_kernel
                         *dst = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                     }
                 }
+            }
         }
     }
     __syncthreads();
@@ -620,6 +665,7 @@ extern "C" int bts_lpg_chain_bwd(const void* x, int dtype, int x_stride, int c0,
     k.wt = (const char*)wt_frags; k.wt_bytes = wt_bytes;
     k.gout = grad_out; k.dx = grad_x; k.dx_stride = grad_x_stride; k.dx_accumulate = accumulate;
     k.fold_elu = x_is_elu_output;
+    k.dx_wide = ((uintptr_t)grad_x & 15) == 0 && grad_x_stride % 8 == 0;
     for (int l = 0; l < n_layers; ++l) {
         BTS_CHECK_ARG(grad_w[l] && grad_w_ld[l] > 0);
         k.dw[l] = grad_w[l]; k.dw_ld[l] = grad_w_ld[l];
