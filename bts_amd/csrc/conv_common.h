@@ -306,10 +306,89 @@ __device__ __forceinline__ void store_block32(const ConvK& a, size_t opix, int c
     }
 }
 
-template <typename T, int WR, int WC, int TM, int TN>
+// Compile-time forms of store_block32 for launches whose epilogue mode is known (full 32-channel blocks, bf16 rows 16-byte aligned):
+// the generic function carries five wave-uniform branches and both dtype paths, which in the persistent conv_halo loop costs ~1500
+// scalar instructions of live-range management around a 60-instruction body (147 SGPR spills).
+__device__ __forceinline__ void store_block32_plain_bf16(const ConvK& a, size_t opix, int cb, int fk, float (&v)[16]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        uint32_t a0 = pack_bf16x2(v[8 * p], v[8 * p + 1]), a1 = pack_bf16x2(v[8 * p + 2], v[8 * p + 3]);
+        uint32_t b0 = pack_bf16x2(v[8 * p + 4], v[8 * p + 5]), b1 = pack_bf16x2(v[8 * p + 6], v[8 * p + 7]);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        *(u32x4_t*)((uint16_t*)a.y + opix * a.y_stride + cb + 8 * (2 * p + fk)) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+    }
+}
+template <bool ACC, bool FOLD>
+__device__ __forceinline__ void store_block32_rmw_bf16(const ConvK& a, size_t opix, int cb, int fk, float (&v)[16]) {
+    u32x4_t oldw[2], yw[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int co = cb + 8 * (2 * p + fk);
+        if (ACC) oldw[p] = *(const u32x4_t*)((const uint16_t*)a.y + opix * a.y_stride + co);
+        if (FOLD) yw[p] = *(const u32x4_t*)((const uint16_t*)a.fold_y + opix * (size_t)a.fold_stride + co);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 * p + e]), __float_as_uint(v[8 * p + 4 + e]), false, false);
+            v[8 * p + e] = __uint_as_float(r[0]);
+            v[8 * p + 4 + e] = __uint_as_float(r[1]);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = v[8 * p + e];
+        if (ACC) {
+            float o[8];
+            BF16::unpack(oldw[p], o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] += o[e];
+        }
+        if (FOLD) {
+            float y[8];
+            BF16::unpack(yw[p], y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] *= elu_dfac(y[e]);
+        }
+        *(u32x4_t*)((uint16_t*)a.y + opix * a.y_stride + cb + 8 * (2 * p + fk)) = BF16::pack(t);
+    }
+}
+
+// EPI (launcher-checked; bf16, Cout % 32 == 0, aligned rows, out_scale == 1): 0 = generic, 1 = ELU + plain 16-byte stores,
+// 2 / 3 / 4 = no activation + read-modify-write (accumulate / ELU fold / both), 5 = no activation + plain 16-byte stores
+template <typename T, int WR, int WC, int TM, int TN, int EPI = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16_t (&acc)[TM][TN], int co_tile, int px_tile, int phase,
                                               int wr, int wc, int frow, int fk) {
     constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+    if constexpr (EPI != 0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int m = px_tile * BN + (wc * TN + j) * 32 + frow;
+            if (m >= a.M) continue;
+            const uint32_t n = fdiv(m, a.fd_hw);
+            const uint32_t rem = m - n * (uint32_t)(a.Hg * a.Wg);
+            const uint32_t y = fdiv(rem, a.fd_w);
+            const uint32_t x = rem - y * a.Wg;
+            const size_t opix = ((size_t)n * a.Hy + (y * a.osc + (phase >> 1))) * a.Wy + (x * a.osc + (phase & 1));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int cb = co_tile * BM + (wr * TM + i) * 32;
+                if (cb >= a.Cout) continue;                       // Cout % 32 == 0: a block is full or absent
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = EPI == 1 ? act_elu_for<T>(acc[i][j][r]) : acc[i][j][r];
+                if constexpr (EPI == 1 || EPI == 5) store_block32_plain_bf16(a, opix, cb, fk, v);
+                else if constexpr (EPI == 2) store_block32_rmw_bf16<true, false>(a, opix, cb, fk, v);
+                else if constexpr (EPI == 3) store_block32_rmw_bf16<false, true>(a, opix, cb, fk, v);
+                else store_block32_rmw_bf16<true, true>(a, opix, cb, fk, v);
+            }
+        }
+        return;
+    }
     // ---- epilogue: lanes <-> pixels, registers <-> channels -------------------------------
 #pragma unroll
     for (int j = 0; j < TN; ++j) {

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvK a) {
 // buffer; a counted s_waitcnt vmcnt((NS-2)*G) (G = DMA instructions per thread per chunk) retires
 // exactly chunk c's group and leaves the younger groups in flight ACROSS the raw s_barrier (a plain
 // __syncthreads() would drain them: hipcc emits vmcnt(0) in front of it while an LDS-DMA is pending).
-template <typename T, int WR, int WC, int TM, int TN, int NS, int PF = 1>
+template <typename T, int WR, int WC, int TM, int TN, int NS, int PF = 1, int EPI = 0>
 __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
     constexpr int NW = WR * WC;                       // waves per workgroup
     constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
         wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the zero-page tail groups before LDS is released
-    conv_epilogue<T, WR, WC, TM, TN>(a, acc, co_tile, px_tile, phase, wr, wc, frow, fk);
+    conv_epilogue<T, WR, WC, TM, TN, EPI>(a, acc, co_tile, px_tile, phase, wr, wc, frow, fk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -584,7 +584,9 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
 // shares one patch across the four phases.  One wave per tile row of 32 pixels; lanes <-> pixels,
 // registers <-> output channels, same epilogue conventions as conv_epilogue.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int TH, int NG, int TPG, bool PERSIST>
+// EPI: epilogue mode fixed at compile time (launcher-checked): 0 = generic, 1 = ELU + plain 16-byte bf16 stores (forward layers),
+// 2..4 = no activation, read-modify-write 16-byte bf16 stores: 2 = accumulate, 3 = ELU fold, 4 = both (data gradients); out_scale == 1
+template <typename T, int TH, int NG, int TPG, bool PERSIST, int EPI = 0>
 __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
     constexpr int TW = 32, PW = TW + 2, PR = (TH + 2) * PW;    // patch rows (pixels)
     constexpr int NT = NG * TPG;                                // taps in total (9 or 16)
@@ -764,6 +766,20 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
     auto epilogue = [&](const f32x16_t (&acc)[NG], int n, int y0, int x0) {
         const int oy = y0 + wave, ox = x0 + frow;
         if (oy >= a.Hg || ox >= a.Wg) return;
+        if constexpr (EPI != 0) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const size_t opix = ((size_t)n * a.Hy + (oy * a.osc + (g >> 1))) * a.Wy + (ox * a.osc + (g & 1));
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = EPI == 1 ? act_elu_for<T>(acc[g][r]) : acc[g][r];
+                if constexpr (EPI == 1) store_block32_plain_bf16(a, opix, co_tile * 32, fk, v);
+                else if constexpr (EPI == 2) store_block32_rmw_bf16<true, false>(a, opix, co_tile * 32, fk, v);
+                else if constexpr (EPI == 3) store_block32_rmw_bf16<false, true>(a, opix, co_tile * 32, fk, v);
+                else store_block32_rmw_bf16<true, true>(a, opix, co_tile * 32, fk, v);
+            }
+            return;
+        }
         float sc = a.out_scale;
         if (a.out_scale_n) sc *= a.out_scale_n[n];
 #pragma unroll
@@ -1910,14 +1926,28 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
     if (halo_on && use_lds_dma() && k.halo_ok && k.Cout <= 64) {
         const int co_tiles = ceil_div(k.Cout, 32);
         const bool one_chunk = k.KV <= 8;       // whole K in one 128-byte channel chunk: persistent variant
+        // compile-time epilogue forms of the persistent variants (BTS_HALO_EPI=0: the generic epilogue, A/B)
+        static const int epi_on = [] { const char* e = getenv("BTS_HALO_EPI"); return (e && e[0] == '0') ? 0 : 1; }();
+        int epi = 0;
+        if (epi_on && one_chunk && T::kBytes == 2 && k.vec_store && k.wide_store && !k.y_f32 && k.Cout % 32 == 0 && k.out_scale == 1.f &&
+            !k.out_scale_n) {
+            if (k.act == BTS_ACT_ELU && !k.accumulate && !k.fold_y) epi = 1;
+            else if (k.act == BTS_ACT_NONE && (k.accumulate || k.fold_y)) epi = k.accumulate ? (k.fold_y ? 4 : 2) : 3;
+        }
         if (k.nphase == 4) {
             const int ntiles = ceil_div(k.Wg, 32) * ceil_div(k.Hg, 8) * k.N;
-            if (one_chunk) hipLaunchKernelGGL((conv_halo<T, 8, 4, 4, true>), dim3(ntiles < 256 ? ntiles : 256, co_tiles), dim3(512), 0, st, k);
+            if (one_chunk && epi == 1) hipLaunchKernelGGL((conv_halo<T, 8, 4, 4, true, 1>), dim3(ntiles < 256 ? ntiles : 256, co_tiles), dim3(512), 0, st, k);
+            else if (one_chunk) hipLaunchKernelGGL((conv_halo<T, 8, 4, 4, true>), dim3(ntiles < 256 ? ntiles : 256, co_tiles), dim3(512), 0, st, k);
             else hipLaunchKernelGGL((conv_halo<T, 8, 4, 4, false>), dim3(ntiles, co_tiles), dim3(512), 0, st, k);
         } else {
             if (one_chunk) {
                 const int ntiles = ceil_div(k.Wg, 32) * ceil_div(k.Hg, 8) * k.N;
-                hipLaunchKernelGGL((conv_halo<T, 8, 1, 9, true>), dim3(ntiles < 256 ? ntiles : 256, co_tiles), dim3(512), 0, st, k);
+                const dim3 grid(ntiles < 256 ? ntiles : 256, co_tiles);
+                if (epi == 1) hipLaunchKernelGGL((conv_halo<T, 8, 1, 9, true, 1>), grid, dim3(512), 0, st, k);
+                else if (epi == 2) hipLaunchKernelGGL((conv_halo<T, 8, 1, 9, true, 2>), grid, dim3(512), 0, st, k);
+                else if (epi == 3) hipLaunchKernelGGL((conv_halo<T, 8, 1, 9, true, 3>), grid, dim3(512), 0, st, k);
+                else if (epi == 4) hipLaunchKernelGGL((conv_halo<T, 8, 1, 9, true, 4>), grid, dim3(512), 0, st, k);
+                else hipLaunchKernelGGL((conv_halo<T, 8, 1, 9, true>), grid, dim3(512), 0, st, k);
             } else {
                 const int ntiles = ceil_div(k.Wg, 32) * ceil_div(k.Hg, 4) * k.N;
                 hipLaunchKernelGGL((conv_halo<T, 4, 1, 9, false>), dim3(ntiles, co_tiles), dim3(256), 0, st, k);
@@ -1983,7 +2013,26 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
             else if (big == 's') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 7>, 128, 128, 256);    // + s_setprio
             else if (big == 'a') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2>, 128, 128, 256);       // round-1 schedule (compiler-placed waits)
             else if (big == 's') go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 7>, 128, 128, 256);
-            else go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8>, 128, 128, 256);                    // default: t
+            else {
+                // default: t, with the epilogue mode compiled in where the launch qualifies (BTS_IGEMM_EPI=0: generic, A/B)
+                static const int epi_on = [] { const char* e = getenv("BTS_IGEMM_EPI"); return (e && e[0] == '0') ? 0 : 1; }();
+                int epi = 0;
+                if (epi_on && T::kBytes == 2 && k.vec_store && k.wide_store && !k.y_f32 && k.Cout % 32 == 0 && k.out_scale == 1.f &&
+                    !k.out_scale_n) {
+                    if (k.act == BTS_ACT_ELU && !k.accumulate && !k.fold_y) epi = 1;
+                    else if (k.act == BTS_ACT_NONE) epi = k.accumulate ? (k.fold_y ? 4 : 2) : (k.fold_y ? 3 : 5);
+                }
+                if constexpr (T::kBytes == 2) {
+                    if (epi == 1) go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 1>, 128, 128, 256);
+                    else if (epi == 2) go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 2>, 128, 128, 256);
+                    else if (epi == 3) go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 3>, 128, 128, 256);
+                    else if (epi == 4) go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 4>, 128, 128, 256);
+                    else if (epi == 5) go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 5>, 128, 128, 256);
+                    else go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8>, 128, 128, 256);
+                } else {
+                    go2(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8>, 128, 128, 256);
+                }
+            }
         }
         else if (k.Cout > 32) go2(conv_igemm_dma<T, 1, 4, 2, 1, 2>, 64, 128, 256);
         else go2(conv_igemm_dma<T, 1, 4, 1, 2, 2>, 32, 256, 256);
