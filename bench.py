@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--parity", type=int, default=1, help="one-batch parity figures (decoder vs the device-side checker) in the JSON line; N=1 only")
     ap.add_argument("--lpg-op", type=int, default=1, help="time the bare LPG operator at the bench shape (BASELINE metric ii); N=1 only")
     ap.add_argument("--dump-launches", default="", help="write the per-launch table of the event-timed steps (family, layer tag, us, work) to this JSON file")
+    ap.add_argument("--f32-line", type=int, default=1, help="also time the f32 configuration (the one that meets the 1e-4 parity bound) in a "
+                    "child process of this run and print it as the `f32` object of the line; N=1, default workload, bf16 only")
+    ap.add_argument("--eager-steps", type=int, default=5, help="N=1: un-profiled eager steps timed after the replayed region (`eager` object: "
+                    "the launch mode an N>1 run uses, so the driver's 1 -> N curve can be read like for like)")
     ap.add_argument("--force-dist", type=int, default=0, help=argparse.SUPPRESS)   # world-1 process group: exercises the N>1 path on one GPU
     return ap.parse_args()
 
@@ -84,17 +88,20 @@ def make_batch(args, dev, seed):
     return image.to(dev), focal.to(dev), gt.to(dev)
 
 
-def cpu_baseline(args, budget_s=30.0):
-    """Oracle train step (encoder fwd + oracle decoder + silog + bwd) on the host cores, f32, bounded sample.
+CPU_CROP = (160, 608)          # fixed sample of the CPU leg: a 160x608 crop (multiples of 32) of the bench image
+CPU_THREAD_SWEEP = (8, 16, 32)
 
-    The sample is ONE image of the bench shape when 1 warm-up + 3 timed iterations of it fit the time budget, otherwise
-    the largest 1/4 or 1/16-area crop that does, scaled to images/s by the pixel ratio (every layer is convolutional,
-    cost is linear in pixels); the reported value is the median of the 3 timed iterations.  Threads: min(host cores, 64) -- PyTorch CPU convs stop scaling long before
-    the 256 hardware threads of the GPU host."""
+
+def cpu_baseline(args):
+    """Oracle train step (stock encoder fwd + oracle decoder + silog + bwd) on the host cores, f32, FIXED bounded sample: one
+    160x608 crop of one image (0.227 of a 352x1216 image; every layer is convolutional, cost is linear in pixels), scaled to
+    images/s by the pixel ratio.  The thread count is chosen by a 3-point sweep (8 / 16 / 32 threads, one warm-up + one timed
+    iteration each; PyTorch's CPU convolutions stop scaling long before the 256 hardware threads of the GPU host and thrash
+    beyond that), then 3 timed iterations at the best count, median reported.  No budget-driven resizing: the same sample on
+    every host, so the figure is comparable between runs (profiles/r02_cpu_reference_vs_port.json holds the unmodified
+    reference timed beside this port on the same crop, 8 threads of the build host)."""
     from bts_amd.model import BtsModel
     from oracle import bts_oracle as O
-    threads = min(os.cpu_count() or 1, 64)
-    torch.set_num_threads(threads)
     params = NS(encoder=args.encoder, max_depth=80.0 if args.dataset == "kitti" else 10.0, dataset=args.dataset, bts_size=512)
     torch.manual_seed(0)
     model = BtsModel(params)            # parameter container only: the oracle does the math
@@ -103,6 +110,7 @@ def cpu_baseline(args, budget_s=30.0):
          for k, v in model.decoder.state_dict().items()}
     gen = torch.Generator().manual_seed(1)
     H, W = args.height, args.width
+    hh, ww = min(CPU_CROP[0], H), min(CPU_CROP[1], W)
     gt = O.synth_depth_gt(1, H, W, args.dataset, gen)
     focal = O.synth_focal(1, args.dataset)
 
@@ -118,26 +126,24 @@ def cpu_baseline(args, budget_s=30.0):
         loss = O.silog(outs[4], g, g > (1.0 if args.dataset == "kitti" else 0.1), 0.85)
         loss.backward()
         return time.time() - t0
-    step(64, 128)                                   # thread-pool / allocator warm-up
-    # choose the largest sample (full image, 1/4 area, 1/16 area) whose 1 warm-up + 3 timed iterations fit the budget
-    h16, w16 = H // 4 // 32 * 32 or 32, W // 4 // 32 * 32 or 32
-    t16 = step(h16, w16)                            # 1/16-area probe
-    per_px = t16 / (h16 * w16)
-    hh, ww = h16, w16
-    for ch, cw in ((H, W), (H // 2 // 32 * 32, W // 2 // 32 * 32)):
-        if per_px * ch * cw * 4 <= budget_s:
-            hh, ww = ch, cw
-            break
-    step(hh, ww)                                    # warm-up at the measured shape
+    ncpu = os.cpu_count() or 1
+    sweep = {}
+    for th in [t for t in CPU_THREAD_SWEEP if t <= ncpu] or [ncpu]:
+        torch.set_num_threads(th)
+        step(hh, ww)                                # warm-up at this thread count (thread pool, allocator, primitive caches)
+        sweep[th] = step(hh, ww)
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
     ts = sorted(step(hh, ww) for _ in range(3))
     dt = ts[1]                                      # median of 3
     frac = (hh * ww) / float(H * W)
     ips = frac / dt
-    return {"value": round(ips, 4), "unit": "images/s", "cores": threads, "host_cpu_count": os.cpu_count(), "kind": "port",
-            "sample": "oracle (stock encoder + oracle decoder + silog) fwd+bwd, f32, batch 1, %dx%d crop = %.4g of one %dx%d image, "
-                      "1 warm-up + 3 timed iterations, median %.2f s (min %.2f, max %.2f), scaled by pixel count; the unmodified "
-                      "reference timed beside this port on the build host: profiles/r02_cpu_reference_vs_port.json"
-                      % (hh, ww, frac, H, W, dt, ts[0], ts[2])}
+    return {"value": round(ips, 4), "unit": "images/s", "cores": threads, "host_cpu_count": ncpu, "kind": "port",
+            "thread_sweep_s": {str(k): round(v, 3) for k, v in sweep.items()},
+            "sample": "oracle (stock encoder + oracle decoder + silog) fwd+bwd, f32, batch 1, fixed %dx%d crop = %.4g of one %dx%d "
+                      "image, threads chosen by the sweep in thread_sweep_s (seconds per iteration), then 3 timed iterations, "
+                      "median %.2f s (min %.2f, max %.2f), scaled by pixel count; the unmodified reference timed beside this port "
+                      "on the build host: profiles/r02_cpu_reference_vs_port.json" % (hh, ww, frac, H, W, dt, ts[0], ts[2])}
 
 
 def cpu_baseline_subprocess(args, timeout_s=240):
@@ -153,8 +159,32 @@ def cpu_baseline_subprocess(args, timeout_s=240):
                 return json.loads(line)
         return {"value": None, "unit": "images/s", "kind": "port", "sample": "cpu baseline failed: %s" % out.stderr[-300:]}
     except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "images/s", "kind": "port", "cores": min(os.cpu_count() or 1, 64),
+        return {"value": None, "unit": "images/s", "kind": "port", "cores": None,
                 "sample": "cpu baseline exceeded %d s on this host and was cut" % timeout_s}
+
+
+def f32_line_subprocess(args, parity, timeout_s=240):
+    """The f32 configuration of the same workload -- the one whose outputs meet north_star's 1e-4 bound (`parity.f32_*`) -- timed by
+    a child of this run (10 steps after 3 warm-up steps, same synthetic batch, hipGraph replay) so that it is part of the
+    driver-visible line.  The child is this script with --dtype f32; its roofline object is that of ITS dominant kernel family."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "f32", "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
+           "--parity", "0", "--lpg-op", "0", "--f32-line", "0", "--eager-steps", "0", "--encoder", args.encoder, "--dataset", args.dataset,
+           "--height", str(args.height), "--width", str(args.width), "--batch", str(args.batch)]
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        for line in reversed(res.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                j = json.loads(line)
+                out = {k: j.get(k) for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline", "mfma_all_convs",
+                                             "hip_kernels_ms_per_step")}
+                out["launch"] = j.get("config", {}).get("launch")
+                if parity:
+                    out["parity"] = {k: v for k, v in parity.items() if k.startswith("f32_")}
+                return out
+        return {"value": None, "error": res.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "error": "f32 child exceeded %d s" % timeout_s}
 
 
 def library_md5():
@@ -212,6 +242,15 @@ def parity_check(args, model, image, focal, dev):
     def mx(a, b):
         a, b = a.double(), b.double()
         return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+    def elem(a, b, q):
+        """ELEMENT-WISE relative error |a - b| / |b| (every output is a positive depth / max_depth map, so |b| > 0): its
+        q-quantile over all pixels (torch.quantile is limited to 16 M elements: kthvalue on the flattened map)."""
+        r = ((a.double() - b.double()).abs() / b.double().abs().clamp_min(1e-30)).flatten()
+        if q >= 1.0:
+            return r.max().item()
+        kth = min(r.numel(), max(1, int(round(q * r.numel()))))
+        return r.float().kthvalue(kth).values.item()
     nb = min(2, image.shape[0])
     md = 80.0 if args.dataset == "kitti" else 10.0
     was_training = model.training
@@ -223,7 +262,8 @@ def parity_check(args, model, image, focal, dev):
             with torch.backends.cudnn.flags(enabled=False):
                 ref, _ = O.decoder_forward(P, feats, focal[:nb], md, args.dataset, True)
             out = {"checker": "oracle formulas (bts.py:196-266), f32 torch ops on the device, same encoder features; train-mode "
-                              "BatchNorm; %d images" % nb}
+                              "BatchNorm; %d images; *_max = max|a-b| / max|b|, *_l2 = ||a-b|| / ||b|| (norm-wise, worst of the five "
+                              "outputs); *_elem_p999 / *_elem_max = 99.9th percentile / maximum of the ELEMENT-WISE |a-b| / |b|" % nb}
             for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
                 dec = bts(NS(max_depth=md, dataset=args.dataset, encoder=args.encoder, bts_size=512, decoder_dtype=dt),
                           model.encoder.feat_out_channels, 512).to(dev)
@@ -232,6 +272,8 @@ def parity_check(args, model, image, focal, dev):
                 got = dec([f.clone() for f in feats], focal[:nb])
                 out["%s_outputs_max" % tag] = float("%.3g" % max(mx(g, r) for g, r in zip(got, ref)))
                 out["%s_outputs_l2" % tag] = float("%.3g" % max(l2(g, r) for g, r in zip(got, ref)))
+                out["%s_outputs_elem_p999" % tag] = float("%.3g" % max(elem(g, r, 0.999) for g, r in zip(got, ref)))
+                out["%s_outputs_elem_max" % tag] = float("%.3g" % max(elem(g, r, 1.0) for g, r in zip(got, ref)))
                 del dec
         out["timed_dtype"] = args.dtype
         return out
@@ -397,18 +439,20 @@ def main():
         model.encoder.to(memory_format=torch.channels_last)
     net = model
     reducer = None
+    bufsync = None
     red_mode = args.reducer
     if red_mode == "auto":
         red_mode = "bts"      # hook-driven GradAllReducer, eager step: measured fastest N>1 form (profiles/r02_bench_dist_world1.md)
     if multi and red_mode == "ddp":
         # ResNet-family backbones carry the unused torchvision head (avgpool/fc): bts_main.py:352 sets find_unused_parameters
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
-                                                        broadcast_buffers=False,
+                                                        broadcast_buffers=True,        # the reference's (default) setting
                                                         find_unused_parameters="resne" in args.encoder)
     elif multi:
-        from bts_amd.parallel import GradAllReducer, broadcast_parameters
+        from bts_amd.parallel import BufferSync, GradAllReducer, broadcast_parameters
         broadcast_parameters(model)
         reducer = GradAllReducer(model.parameters(), reduce_single=bool(args.force_dist))
+        bufsync = BufferSync(model)      # DDP's broadcast_buffers=True (bts_main.py:352): rank 0's BatchNorm buffers before every forward
     use_graph = bool(args.graph) and not multi
     split_graph = multi and red_mode == "bts-graph"
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
@@ -436,6 +480,7 @@ def main():
     def step_body():
         if reducer is not None:
             reducer.zero_grad()                      # flat buckets own the gradients
+            bufsync()
         else:
             opt.zero_grad(set_to_none=not own_opt)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
@@ -529,6 +574,8 @@ def main():
         if graph is None:
             return step_eager()
         set_lr()
+        if graph_b is not None:
+            bufsync()                 # outside the captured graphs, like the gradient exchange
         graph.replay()
         if graph_b is not None:
             reducer.reduce_all()
@@ -556,6 +603,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss.item())
+    eager = None
+    if world == 1 and graph is not None and args.eager_steps > 0:
+        # the same step issued launch by launch from Python (no graph, no per-launch events): what `--gpus N` (N > 1) runs
+        step_eager()
+        torch.cuda.synchronize()
+        t1 = time.time()
+        for _ in range(args.eager_steps):
+            step_eager()
+        torch.cuda.synchronize()
+        e_ms = (time.time() - t1) / args.eager_steps * 1e3
+        eager = {"ms_per_step": round(e_ms, 3), "value": round(args.batch / e_ms * 1e3, 3), "unit": "images/s", "steps": args.eager_steps,
+                 "note": "eager launch mode at N=1, un-profiled; an N>1 line (eager step + hook-driven gradient exchange) compares with THIS, "
+                         "not with the replayed `value`"}
     if (graph is not None or world > 1) and not args.no_kernel_events and (rank == 0 or world > 1):
         # events cannot be recorded inside a graph replay: time the same kernels over the same number of
         # eager steps right after the timed region (same process, same buffers, same clocks).  With N > 1 every rank runs
@@ -603,6 +663,11 @@ def main():
             out.update(roof)
         if parity is not None:
             out["parity"] = parity
+        if eager is not None:
+            out["eager"] = eager
+        if (args.f32_line and world == 1 and args.dtype == "bf16" and not multi
+                and (args.encoder, args.height, args.width, args.batch) == ("densenet161_bts", 352, 1216, 8)):
+            out["f32"] = f32_line_subprocess(args, parity)
         if args.lpg_op and world == 1:
             try:
                 out["roofline_lpg_op"] = lpg_op_roofline(args.batch, args.height, args.width)

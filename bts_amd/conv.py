@@ -74,6 +74,8 @@ def _wide_pays(cout, n, hg, wg):
     if mode == "2":
         return True
     bm = 128 if cout > 64 else 64
+    if cout > 64 and cout % 96 == 0 and cout % 128 != 0 and os.environ.get("BTS_WIDE_96", "1")[:1] != "0":
+        bm = 96
     ntiles = _cdiv(wg, 32) * _cdiv(hg, 8) * n
     nco = _cdiv(cout, bm)
     wgs = ntiles * nco
@@ -94,6 +96,8 @@ def _fwd_kernel(dtype, cout, halo, geom=None, kv=8, up=False):
     if halo and cout <= 64:
         return "conv_halo<%s>" % _dn(dtype)
     if halo and not up and dtype == torch.bfloat16 and kv >= 8 and geom is not None and _wide_pays(cout, *geom):
+        if cout > 64 and cout % 96 == 0 and cout % 128 != 0 and os.environ.get("BTS_WIDE_96", "1")[:1] != "0":
+            return "conv_halo_wide<bf16,96x256>"
         return "conv_halo_wide<bf16,128x256>"
     if cout > 64 and geom is not None:
         big = os.environ.get("BTS_CONV_BIG", _CONV_BIG_DEFAULT)[:1]

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(TH* TW) void conv_c1_fwd_kernel(const void* __restr
 // registers, each 16-byte vector read exactly once and never staged),  y[p] = sigmoid(sum_t s_t[p + t]) * scale  (nine scalars per
 // output pixel through LDS: 36 B written + 36 B read per pixel).  Thread = (pixel lane, 16-byte channel vector) with its 9 x V
 // weights in registers; the partial dot products of a pixel's CV lanes meet by DPP (quad) / bpermute butterflies.
-template <typename T, int TH, int TW>
+template <typename T, int TH, int TW, int CV>
 __global__ __launch_bounds__(256) void conv_c1_fwd2_kernel(const void* __restrict__ x, int xs, int C, const float* __restrict__ w,
                                                            float* __restrict__ y, int N, int H, int W, float out_scale,
                                                            const float* __restrict__ out_scale_n) {
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void conv_c1_fwd2_kernel(const void* __restric
     __shared__ float S[9 * PR];
     __shared__ float sw[9 * 64];
     const int tid = threadIdx.x;
-    const int CV = C / V;                                             // power of two <= 16 (launcher)
-    const int cv = tid & (CV - 1), pl = tid / CV, NPL = 256 / CV;
+    constexpr int NPL = 256 / CV;                                      // CV = C / V: a compile-time power of two <= 16 (launcher)
+    const int cv = tid & (CV - 1), pl = tid / CV;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     int tile = blockIdx.x;
     const int tx0 = (tile % tiles_x) * TW;
@@ -176,15 +176,21 @@ __global__ __launch_bounds__(256) void conv_c1_fwd2_kernel(const void* __restric
                 for (int t = 0; t < 9; ++t)
                     st[t] += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(st[t]), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
             }
+#pragma unroll
             for (int m = 4; m < CV; m <<= 1) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) st[t] += __shfl_xor(st[t], m);
             }
-            // every lane of the pixel now holds all nine sums; lane cv stores taps cv, cv + CV, ...
-            if (i < PR) {
+            // every lane of the pixel now holds all nine sums; lane cv stores taps cv, cv + CV, ...: the value is picked with selects
+            // (a predicated store per tap costs an exec-mask round trip each) and the store count is a compile-time constant
 #pragma unroll
-                for (int t = 0; t < 9; ++t)
-                    if ((t & (CV - 1)) == cv) S[t * PR + i] = st[t];
+            for (int k = 0; k * CV < 9; ++k) {
+                float val = st[CV * k];
+#pragma unroll
+                for (int j = 1; j < CV; ++j)
+                    if (CV * k + j < 9) val = cv == j ? st[CV * k + j] : val;
+                const int t = CV * k + cv;
+                if (t < 9 && i < PR) S[t * PR + i] = val;
             }
         }
     }
@@ -418,12 +424,13 @@ extern "C" int bts_conv3x3_c1_fwd(const void* x, int dtype, int x_stride, int C,
         // the same within 2 % (gpurun r03ad: 76-81 us bf16): the kernel is bound by its ~125 VALU operations per input vector.
         constexpr int TH = 16, TW = 64;
         const long tiles = (long)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-        if (dtype == BTS_BF16)
-            hipLaunchKernelGGL((conv_c1_fwd2_kernel<BF16, TH, TW>), dim3((unsigned)tiles), dim3(256), 0, st, x, x_stride, C, w, y, N, H, W,
-                               out_scale, out_scale_n);
-        else
-            hipLaunchKernelGGL((conv_c1_fwd2_kernel<F32, TH, TW>), dim3((unsigned)tiles), dim3(256), 0, st, x, x_stride, C, w, y, N, H, W,
-                               out_scale, out_scale_n);
+#define L_(TT, CC) hipLaunchKernelGGL((conv_c1_fwd2_kernel<TT, TH, TW, CC>), dim3((unsigned)tiles), dim3(256), 0, st, x, x_stride, C, w, y, N, H, W, \
+                                      out_scale, out_scale_n)
+#define LC_(TT) do { switch (C / V) { case 1: L_(TT, 1); break; case 2: L_(TT, 2); break; case 4: L_(TT, 4); break;            \
+                                      case 8: L_(TT, 8); break; default: L_(TT, 16); break; } } while (0)
+        if (dtype == BTS_BF16) LC_(BF16); else LC_(F32);
+#undef LC_
+#undef L_
         BTS_LAUNCH_CHECK();
         return BTS_OK;
     }

@@ -40,17 +40,18 @@ constexpr int PBYTES = PR_PAD * 128;
 // of LDS) or 2 (64 co, r3: conv2 forward -- 161 -> 64 channels at half resolution, until then on the unpipelined conv_halo with its
 // patch staged once per 32-channel tile; 2 x 48 + 4 x 8 = 128 KiB)
 template <int NCO>
-constexpr int wide_lds_bytes() { return 2 * PBYTES + NWS * NCO * 32 * 128; }
+constexpr int wide_lds_bytes() { return 2 * PBYTES + NWS * ((NCO * 32 + RP - 1) / RP) * RP * 128; }
 static_assert(wide_lds_bytes<4>() <= 160 * 1024, "conv_halo_wide: patch double buffer + weight ring exceed the 160 KiB of a CU");
 
-template <int NCO>
+// EPI: epilogue mode fixed at compile time (conv_common.h, conv_epilogue): 0 = generic, 1 = ELU + plain stores, 2 / 3 / 4 = read-modify-write
+// (accumulate / ELU fold / both)
+template <int NCO, int EPI = 0>
 __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
     using T = BF16;
     constexpr int VEC = T::kVec, ES = T::kBytes;
     constexpr int BM = NCO * 32;                                       // output channels per workgroup
-    constexpr int WPASS = BM / RP;                                     // weight pieces per thread per tap (2 / 1)
-    constexpr int WBYTES = BM * 128;
-    static_assert(BM % RP == 0, "whole DMA passes per tap");
+    constexpr int WPASS = (BM + RP - 1) / RP;                          // weight pieces per thread per tap (2 / 1); NCO = 3: the second
+    constexpr int WBYTES = WPASS * RP * 128;                           // piece is half zero page (rows 96..127 of the stage are never read)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sPatch = smem;
     char* sWring = smem + 2 * PBYTES;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
 #pragma unroll
     for (int q = 0; q < WPASS; ++q) {
         const int co = co_tile * BM + q * RP + srow;
-        wrow[q] = co < a.Cout ? a.w + (size_t)co * a.Ttot * a.Ktot * ES : nullptr;
+        wrow[q] = (q * RP + srow < BM && co < a.Cout) ? a.w + (size_t)co * a.Ttot * a.Ktot * ES : nullptr;
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
     // B fragment of (tap, k-step): patch row prow = (wave+1+dy)*PW + frow+1+dx, byte offset prow*128 + swizzled 16-byte slot.
@@ -270,6 +271,21 @@ __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
     float sc = a.out_scale;
     if (a.out_scale_n) sc *= a.out_scale_n[n];
     const size_t opix = ((size_t)n * a.Hy + oy) * a.Wy + ox;
+    if constexpr (EPI != 0) {
+#pragma unroll
+        for (int i = 0; i < NCO; ++i) {
+            const int cb = co_tile * BM + i * 32;
+            if (cb >= a.Cout) continue;                               // Cout % 32 == 0 (launcher): a block is full or absent
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = EPI == 1 ? act_elu_bf16(acc[i][r]) : acc[i][r];
+            if constexpr (EPI == 1) store_block32_plain_bf16(a, opix, cb, fk, v);
+            else if constexpr (EPI == 2) store_block32_rmw_bf16<true, false>(a, opix, cb, fk, v);
+            else if constexpr (EPI == 3) store_block32_rmw_bf16<false, true>(a, opix, cb, fk, v);
+            else store_block32_rmw_bf16<true, true>(a, opix, cb, fk, v);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NCO; ++i) {
         float v[16];
@@ -306,9 +322,25 @@ static int launch_halo_wide_n(ConvK& k, hipStream_t st, int force) {
         static const double min_fill = [] { const char* e = getenv("BTS_WIDE_FILL"); return e ? atof(e) : 0.60; }();
         if (fill < min_fill) return BTS_ERR_UNSUPPORTED;
     }
-    static DynLdsCache lds_set;
-    if (ensure_dyn_lds((const void*)conv_halo_wide<NCO>, LDS_BYTES, lds_set) != BTS_OK) return BTS_ERR_LAUNCH;
-    hipLaunchKernelGGL(conv_halo_wide<NCO>, dim3((unsigned)(ntiles * k.n_co_tiles)), dim3(NTHR), (size_t)LDS_BYTES, st, k);
+    static const int epi_on = [] { const char* e = getenv("BTS_WIDE_EPI"); return (e && e[0] == '0') ? 0 : 1; }();
+    int epi = 0;
+    if (epi_on && k.vec_store && k.wide_store && !k.y_f32 && k.Cout % 32 == 0 && k.out_scale == 1.f && !k.out_scale_n) {
+        if (k.act == BTS_ACT_ELU && !k.accumulate && !k.fold_y) epi = 1;
+        else if (k.act == BTS_ACT_NONE && (k.accumulate || k.fold_y)) epi = k.accumulate ? (k.fold_y ? 4 : 2) : 3;
+    }
+    static DynLdsCache lds_set[5];
+    const dim3 grid((unsigned)(ntiles * k.n_co_tiles));
+#define BTS_WIDE_(E)                                                                                                       \
+    do {                                                                                                                   \
+        if (ensure_dyn_lds((const void*)conv_halo_wide<NCO, E>, LDS_BYTES, lds_set[E]) != BTS_OK) return BTS_ERR_LAUNCH;   \
+        hipLaunchKernelGGL((conv_halo_wide<NCO, E>), grid, dim3(NTHR), (size_t)LDS_BYTES, st, k);                          \
+    } while (0)
+    if (epi == 1) BTS_WIDE_(1);
+    else if (epi == 2) BTS_WIDE_(2);
+    else if (epi == 3) BTS_WIDE_(3);
+    else if (epi == 4) BTS_WIDE_(4);
+    else BTS_WIDE_(0);
+#undef BTS_WIDE_
     if (hipGetLastError() != hipSuccess) return BTS_ERR_LAUNCH;
     return BTS_OK;
 }
@@ -317,7 +349,12 @@ int launch_halo_wide(const ConvK& k0, hipStream_t st, int force) {
     ConvK k = k0;
     if (!(k.halo_ok && k.nphase == 1 && k.T == 9 && k.osc == 1 && k.Cout > 32)) return BTS_ERR_UNSUPPORTED;
     if (!segs_fit_u32(k)) return BTS_ERR_UNSUPPORTED;                  // ppix * sb is a 32-bit product in the kernel
-    return k.Cout > 64 ? launch_halo_wide_n<4>(k, st, force) : launch_halo_wide_n<2>(k, st, force);
+    if (k.Cout <= 64) return launch_halo_wide_n<2>(k, st, force);
+    // 96-channel tiles where they divide the output exactly and 128-channel tiles do not (DenseNet161's 96 / 192-channel skips:
+    // 0.75 of a 128-channel tile's MFMAs and fragment reads); BTS_WIDE_96=0: A/B
+    static const int w96_on = [] { const char* e = getenv("BTS_WIDE_96"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (w96_on && k.Cout % 96 == 0 && k.Cout % 128 != 0) return launch_halo_wide_n<3>(k, st, force);
+    return launch_halo_wide_n<4>(k, st, force);
 }
 
 }  // namespace bts_conv

@@ -1929,7 +1929,7 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
         // compile-time epilogue forms of the persistent variants (BTS_HALO_EPI=0: the generic epilogue, A/B)
         static const int epi_on = [] { const char* e = getenv("BTS_HALO_EPI"); return (e && e[0] == '0') ? 0 : 1; }();
         int epi = 0;
-        if (epi_on && one_chunk && T::kBytes == 2 && k.vec_store && k.wide_store && !k.y_f32 && k.Cout % 32 == 0 && k.out_scale == 1.f &&
+        if (epi_on && T::kBytes == 2 && k.vec_store && k.wide_store && !k.y_f32 && k.Cout % 32 == 0 && k.out_scale == 1.f &&
             !k.out_scale_n) {
             if (k.act == BTS_ACT_ELU && !k.accumulate && !k.fold_y) epi = 1;
             else if (k.act == BTS_ACT_NONE && (k.accumulate || k.fold_y)) epi = k.accumulate ? (k.fold_y ? 4 : 2) : 3;
@@ -1938,6 +1938,7 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
             const int ntiles = ceil_div(k.Wg, 32) * ceil_div(k.Hg, 8) * k.N;
             if (one_chunk && epi == 1) hipLaunchKernelGGL((conv_halo<T, 8, 4, 4, true, 1>), dim3(ntiles < 256 ? ntiles : 256, co_tiles), dim3(512), 0, st, k);
             else if (one_chunk) hipLaunchKernelGGL((conv_halo<T, 8, 4, 4, true>), dim3(ntiles < 256 ? ntiles : 256, co_tiles), dim3(512), 0, st, k);
+            else if (epi == 1) hipLaunchKernelGGL((conv_halo<T, 8, 4, 4, false, 1>), dim3(ntiles, co_tiles), dim3(512), 0, st, k);
             else hipLaunchKernelGGL((conv_halo<T, 8, 4, 4, false>), dim3(ntiles, co_tiles), dim3(512), 0, st, k);
         } else {
             if (one_chunk) {
@@ -1950,7 +1951,8 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
                 else hipLaunchKernelGGL((conv_halo<T, 8, 1, 9, true>), grid, dim3(512), 0, st, k);
             } else {
                 const int ntiles = ceil_div(k.Wg, 32) * ceil_div(k.Hg, 4) * k.N;
-                hipLaunchKernelGGL((conv_halo<T, 4, 1, 9, false>), dim3(ntiles, co_tiles), dim3(256), 0, st, k);
+                if (epi == 1) hipLaunchKernelGGL((conv_halo<T, 4, 1, 9, false, 1>), dim3(ntiles, co_tiles), dim3(256), 0, st, k);
+                else hipLaunchKernelGGL((conv_halo<T, 4, 1, 9, false>), dim3(ntiles, co_tiles), dim3(256), 0, st, k);
             }
         }
         BTS_LAUNCH_CHECK();
@@ -2034,8 +2036,28 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
                 }
             }
         }
-        else if (k.Cout > 32) go2(conv_igemm_dma<T, 1, 4, 2, 1, 2>, 64, 128, 256);
-        else go2(conv_igemm_dma<T, 1, 4, 1, 2, 2>, 32, 256, 256);
+        else {
+            // narrow tiles: the same compile-time epilogue forms as the default schedule above
+            static const int epi_on = [] { const char* e = getenv("BTS_IGEMM_EPI"); return (e && e[0] == '0') ? 0 : 1; }();
+            int epi = 0;
+            if (epi_on && T::kBytes == 2 && k.vec_store && k.wide_store && !k.y_f32 && k.Cout % 32 == 0 && k.out_scale == 1.f && !k.out_scale_n) {
+                if (k.act == BTS_ACT_ELU && !k.accumulate && !k.fold_y) epi = 1;
+                else if (k.act == BTS_ACT_NONE) epi = k.accumulate ? (k.fold_y ? 4 : 2) : (k.fold_y ? 3 : 5);
+            }
+#define BTS_NARROW_(E) do { if (k.Cout > 32) go2(conv_igemm_dma<T, 1, 4, 2, 1, 2, 1, E>, 64, 128, 256);      \
+                            else go2(conv_igemm_dma<T, 1, 4, 1, 2, 2, 1, E>, 32, 256, 256); } while (0)
+            if constexpr (T::kBytes == 2) {
+                if (epi == 1) BTS_NARROW_(1);
+                else if (epi == 2) BTS_NARROW_(2);
+                else if (epi == 3) BTS_NARROW_(3);
+                else if (epi == 4) BTS_NARROW_(4);
+                else if (epi == 5) BTS_NARROW_(5);
+                else BTS_NARROW_(0);
+            } else {
+                BTS_NARROW_(0);
+            }
+#undef BTS_NARROW_
+        }
     } else {
         if (k.Cout > 64) go(conv_igemm<T, 2, 2, 2, 2>, 128, 128);
         else if (k.Cout > 32) go(conv_igemm<T, 1, 4, 2, 2>, 64, 256);

@@ -278,14 +278,44 @@ int dispatch_chain(const ChainK& k, int c0, int same_first, int kup, hipStream_t
 // a_l are transposed through a per-wave LDS scratch (ds_write_b16 rows [channel][32 cells], read back as 16-byte
 // fragments) and accumulated in registers over every tile the wave owns; one cross-wave LDS reduction and one set of
 // atomics per workgroup at the end.  HBM traffic: x once, grad_out once, dx once (+ read when accumulating).
-constexpr int RS = 80;   // scratch row stride in bytes: 32 cells * 2 B + 16 B skew
+constexpr int RS = 80;   // (cross-wave reduction scratch granularity; the transposes no longer use channel-major rows)
+
+// Transposes through ds_read_b64_tr_b16 (r4 candidate): the register images are written CELL-major, as they are held -- one 16-byte
+// (layer-0 input order) or two 8-byte (accumulator order) stores per vector instead of eight ds_write_b16 -- into rows of one cell
+// each, `cell_pitch<C>()` bytes apart; a fragment (32 channels x 16 cells) is two transposing reads: a 16-lane group reads [4 cells][16
+// channels] and every lane receives one channel's 4 cells, so the 8 K values of a lane are cells 8 kb .. 8 kb + 7 exactly as before.
+template <int C>
+constexpr int cell_pitch() { return ((C + 31) / 32) * 64 + 16; }
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t tr_frag16(const char* p, int pitch) {
+    typedef __attribute__((address_space(3))) v4s_t* lds_v4s_t;
+    const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)p);
+    const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)(p + 4 * pitch));
+    const uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+    return u32x4_t{l.x, l.y, h.x, h.y};
+}
+// rows[cell][channel] <- register image (NATURAL: layer-0 input order, else accumulator order)
+template <int C, bool NATURAL>
+__device__ __forceinline__ void store_cells(const Act<BF16>::Regs<C>& a, char* rows, int cl, int g) {
+    constexpr int KS = (C < 16 ? 16 : C) / 16, P = cell_pitch<C>();
+    char* base = rows + cl * P;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if constexpr (NATURAL) {
+            *(u32x4_t*)(base + (16 * s + 8 * g) * 2) = a.v[s];                   // channels 16 s + 8 g + 0..7
+        } else {
+            *(uint2*)(base + (16 * s + 4 * g) * 2) = make_uint2(a.v[s].x, a.v[s].y);          // channels 16 s + 4 g + 0..3
+            *(uint2*)(base + (16 * s + 8 + 4 * g) * 2) = make_uint2(a.v[s].z, a.v[s].w);      // channels 16 s + 8 + 4 g + 0..3
+        }
+    }
+}
 
 // scratch rows of one wave: the widest layer's (32-row padded) dz + a_in operands.  Every layer reuses the same rows:
 // stale rows beyond a narrower layer's channels only feed dW rows / columns that are never written out.
 template <int C, int NOUT>
-constexpr int bwd_scr_rows() {
+constexpr int bwd_scr_rows() {       // in units of RS bytes: 32 cells x (dz pitch + a_in pitch) of the widest (= first) layer
     constexpr int cout = C > 8 ? C / 2 : NOUT;
-    return 32 * ((cout + 31) / 32) + 32 * ((C + 31) / 32);
+    return (32 * (cell_pitch<cout>() + cell_pitch<C>()) + RS - 1) / RS;
 }
 template <int C, int NOUT>
 constexpr int bwd_dw_tiles() {
@@ -439,19 +469,23 @@ struct BwdLayer {
             dz.v[0] = z;
         }
         // weight gradient: dW[co][ci] += sum_cells dz[co][cell] * a_in[ci][cell]
+        constexpr int ZP = cell_pitch<COUT>(), AP = cell_pitch<C>();
         char* zr = scr;
-        char* ar = scr + 32 * TMO * RS;
-        scatter_rows<COUT, false>(dz, zr, t.cl, t.g);
-        scatter_rows<C, FIRST>(a_in, ar, t.cl, t.g);
+        char* ar = scr + 32 * ZP;
+        store_cells<COUT, false>(dz, zr, t.cl, t.g);
+        store_cells<C, FIRST>(a_in, ar, t.cl, t.g);
         __builtin_amdgcn_wave_barrier();
+        // this lane's piece of a [4 cells][16 channels] block: cell row 8 kb + key, 8-byte channel group cg of the 16-channel half chh
+        const int i16 = t.lane & 15, g4 = t.lane >> 4;
+        const int trow = (g4 >> 1) * 8 + (i16 >> 2), tcol = (g4 & 1) * 32 + (i16 & 3) * 8;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             u32x4_t bf[TNI];
 #pragma unroll
-            for (int tn = 0; tn < TNI; ++tn) bf[tn] = *(const u32x4_t*)(ar + (32 * tn + t.cl) * RS + (16 * s + 8 * t.g) * 2);
+            for (int tn = 0; tn < TNI; ++tn) bf[tn] = tr_frag16(ar + (16 * s + trow) * AP + 64 * tn + tcol, AP);
 #pragma unroll
             for (int tm = 0; tm < TMO; ++tm) {
-                const u32x4_t af = *(const u32x4_t*)(zr + (32 * tm + t.cl) * RS + (16 * s + 8 * t.g) * 2);
+                const u32x4_t af = tr_frag16(zr + (16 * s + trow) * ZP + 64 * tm + tcol, ZP);
 #pragma unroll
                 for (int tn = 0; tn < TNI; ++tn)
                     dw[T0 + tm * TNI + tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(

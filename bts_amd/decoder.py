@@ -12,7 +12,6 @@ statistics, LPG heads and the five outputs are f32.  torch.cat never happens: ev
 its concatenated input as a list of segments.
 """
 import ctypes as C
-import os
 
 import torch
 
@@ -25,13 +24,9 @@ from .ops import pad_to, vec_of
 
 KITTI_FOCAL_REF = 715.0873  # bts.py:264
 BN_MOMENTUM = 0.01          # bts.py:154 etc.
-# fused recompute backward of the narrow LPG chains (A/B switch for measurements: BTS_CHAIN_BWD=0 trains them layer-wise)
-FUSED_CHAIN_BWD = os.environ.get("BTS_CHAIN_BWD", "1") != "0"
-# ELU derivative folded into the launch that completes the gradient of a conv+ELU output (A/B switch: BTS_FOLD_ELU=0 runs the
-# separate act_bwd pass per convolution, as round 2 did)
-FOLD_ELU = os.environ.get("BTS_FOLD_ELU", "1") != "0"
-# get_depth on the streaming one-output-channel kernels (csrc/conv_c1.hip); BTS_CONV_C1=0: the MFMA kernels (A/B)
-USE_CONV_C1 = os.environ.get("BTS_CONV_C1", "1") != "0"
+# fused recompute backward of the narrow LPG chains; the tests flip this module constant to train the chains layer by layer
+# (the layer-wise path is the checker of the fused one, tests/test_gpu_2_decoder.py)
+FUSED_CHAIN_BWD = True
 
 
 def reduction_specs(c_in, c_out, is_final):
@@ -153,7 +148,6 @@ class PackSet:
         self.fblocks = self._assign(fjobs, lambda j: _cdiv(j.R if j.mode == 0 else j.K, 32) * _cdiv(j.K if j.mode == 0 else j.R, 32))
         self.dblocks = self._assign(djobs, lambda j: _cdiv(j.R if j.mode == 0 else j.K, 32) * _cdiv(j.K if j.mode == 0 else j.R, 32))
         self.ublocks = self._assign(ujobs, lambda j: _cdiv(j.Cout * j.Cin, 256))
-        self.prepacked = None      # (event, dgrad_too) of a side-stream repack issued by prepack(): consumed by the next pass
         self.fjobs, self.nf = self._upload(fjobs, dev), len(fjobs)
         self.djobs, self.nd = self._upload(djobs, dev), len(djobs)
         self.ujobs, self.nu = self._upload(ujobs, dev), len(ujobs)
@@ -192,20 +186,6 @@ class PackSet:
         _lib.call("bts_pack_weight_batch", C.c_void_p(self.djobs.data_ptr()), self.nd, self.dblocks, _lib.dtype_code(self.dtype),
                   _lib.stream_ptr())
 
-    def prepack(self, side, with_dgrad):
-        """Repack on stream `side` behind everything already queued on the current stream (the optimizer's update of the weights);
-        the next DecoderRun waits for the recorded event instead of packing in line.  BtsModel.forward calls this BEFORE the
-        encoder, so the two launches (110 us each at DenseNet161 width: 82 MB of f32 weights in, 41 MB of bf16 operands out)
-        run under the encoder's kernels instead of in front of the decoder's."""
-        side.wait_stream(torch.cuda.current_stream(side.device))
-        with torch.cuda.stream(side):
-            self.pack_forward()
-            if with_dgrad:
-                self.pack_dgrad()
-            ev = torch.cuda.Event()
-            ev.record(side)
-        self.prepacked = (ev, bool(with_dgrad))
-
     def unpack_all(self, dwp_arena, gw_arena):
         if profiler.ACTIVE is not None:
             profiler.note("unpack_wgrad_batch", "hbm", (self.dwp_total + self.gw_total) * 4)
@@ -231,7 +211,6 @@ class DecoderRun:
             ps = PackSet(plan, P, dtype)
             plan.pack_cache[(dtype, dev)] = ps
         self.packs = ps
-        self.dgrad_packed = False
         self.dwp_arena = None
 
     # ---- ops -------------------------------------------------------------------------------
@@ -242,7 +221,7 @@ class DecoderRun:
         has the fold (convolution data-gradients, the fused chain backward, the BatchNorm backward)."""
         first = a.uses == 0
         a.uses += 1
-        return bool(self.record and FOLD_ELU and first and can_fold and a.act == ACT_ELU and a.t.dim() == 4)
+        return bool(self.record and first and can_fold and a.act == ACT_ELU and a.t.dim() == 4)
 
     def feature(self, f, relu=False):
         """Encoder feature (NCHW, f32 or bf16 under autocast) -> NHWC activation; no intermediate casts."""
@@ -259,6 +238,8 @@ class DecoderRun:
     def conv(self, name, segs, act, out_map=False, out_f32=False, out_scale=1.0, out_scale_n=None):
         L = self.plan.layers[name]
         wp = self.packs.fwd[name]
+        if len({id(s) for s in segs}) != len(segs):       # the ELU-fold bookkeeping (one fold per Act) relies on it
+            raise BtsAmdError("conv %s: the same activation passed as two input segments" % name)
         x = [s.t for s in segs]
         N, Hx, Wx, _ = x[0].shape
         Ho, Wo = (2 * Hx, 2 * Wx) if L.up else (Hx, Wx)
@@ -301,9 +282,10 @@ class DecoderRun:
         csrc/conv_c1.hip: forward, data gradient and weight gradient (the sigmoid derivative is formed inside the two backward
         kernels; no dz map exists).  Falls back to the generic convolution outside their domain."""
         L = self.plan.layers[name]
-        if not (USE_CONV_C1 and L.cout == 1 and L.kk == 9 and L.dil == 1 and not L.up and ops.conv_c1_supported(x.t)):
-            return self.conv(name, [x], ACT_SIGMOID, out_map=True, out_scale=out_scale, out_scale_n=out_scale_n)
         w = self.P[name + ".weight"]
+        # the streaming kernels index w[c * 9 + tap] for every c below x's PADDED channel count: only when no channel is padding
+        if not (L.cout == 1 and L.kk == 9 and L.dil == 1 and not L.up and ops.conv_c1_supported(x.t, w)):
+            return self.conv(name, [x], ACT_SIGMOID, out_map=True, out_scale=out_scale, out_scale_n=out_scale_n)
         y = Act(ops.conv3x3_c1_fwd(x.t, w, out_scale, out_scale_n))
         fold = self._use(x, True)
         if self.record:
@@ -363,7 +345,7 @@ class DecoderRun:
         y = Act(out)
         y2 = Act(out2) if relu_copy else None
         firsts = [self._use(sg, True) for sg in segs]
-        fold = x_act == ACT_ELU and len(segs) == 1 and (firsts[0] or not FOLD_ELU)
+        fold = x_act == ACT_ELU and len(segs) == 1 and firsts[0]
         if x_act != ACT_NONE and len(segs) != 1:
             raise BtsAmdError("bn_cat: x_act is only supported for a single ELU input")
         if self.record:
@@ -533,12 +515,7 @@ class DecoderRun:
     # ---- schedule (bts.forward, bts.py:196-266) ------------------------------------------------
     def forward(self, features, focal):
         f = features
-        if self.packs.prepacked is not None:              # side-stream repack issued before the encoder (BtsModel.forward)
-            ev, self.dgrad_packed = self.packs.prepacked
-            self.packs.prepacked = None
-            torch.cuda.current_stream(f[0].device).wait_event(ev)
-        else:
-            self.packs.pack_forward()
+        self.packs.pack_forward()
         N, _, H2, W2 = f[0].shape
         H, W = 2 * H2, 2 * W2
         s0, s1, s2, s3 = (self.feature(f[i]) for i in range(4))
@@ -581,8 +558,7 @@ class DecoderRun:
                 # the LPG maps also receive gradient through conv1/conv3/conv2: own the buffer
                 o.g = g.reshape(o.t.shape).to(torch.float32).clone(memory_format=torch.contiguous_format)
         dev = next(iter(self.packs.fwd.values())).device
-        if not self.dgrad_packed:
-            self.packs.pack_dgrad()
+        self.packs.pack_dgrad()
         self.dwp_arena = torch.zeros(self.packs.dwp_total, dtype=torch.float32, device=dev)     # one memset for every layer
         for fn in reversed(self.tape):
             fn()

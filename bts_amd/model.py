@@ -16,7 +16,6 @@ device raises.
 """
 
 import operator
-import os
 
 import torch
 import torch.nn as nn
@@ -339,36 +338,11 @@ class bts(nn.Module):
         self._plan = DecoderPlan(f, nf)
         self._param_names = tuple(n for n, _ in self.named_parameters())
         self._param_getters = tuple(operator.attrgetter(n) for n in self._param_names)
-        self._pack_streams = {}        # device -> side stream of prepack()
         # activation dtype of the decoder kernels: f32 (parity) or bf16 (throughput); not a parameter
         self.compute_dtype = getattr(params, "decoder_dtype", torch.float32)
         if isinstance(self.compute_dtype, str):
             self.compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32,
                                   "float32": torch.float32}[self.compute_dtype]
-
-    def prepack(self):
-        """Start this step's weight repacking on a side stream (overlaps whatever the caller runs next: the encoder)."""
-        names = self._param_names
-        params = tuple(g(self) for g in self._param_getters)
-        # Off by default: measured (gpurun r03j, whole step replayed from one hipGraph) 60.2 ms with the fork against 58.6 ms
-        # without -- the two 110-us launches do disappear from the decoder's critical path, but a captured graph with a second
-        # branch replays slower on this ROCm than a single-stream one, and the encoder is not short of work to overlap with.
-        # BTS_PREPACK=1 turns it on (eager multi-stream runs).
-        if not params or not params[0].is_cuda or os.environ.get("BTS_PREPACK", "0") != "1":
-            return
-        from .decoder import PackSet
-        P = dict(zip(names, (p.detach() for p in params)))
-        dt, dev = self.compute_dtype, params[0].device
-        layer_names = list(self._plan.layers)
-        key = (dt, tuple(P[n + ".weight"].data_ptr() for n in layer_names))
-        ps = self._plan.pack_cache.get((dt, dev))
-        if ps is None or ps.key != key:
-            ps = PackSet(self._plan, P, dt)
-            self._plan.pack_cache[(dt, dev)] = ps
-        side = self._pack_streams.get(dev)
-        if side is None:
-            side = self._pack_streams[dev] = torch.cuda.Stream(device=dev)
-        ps.prepack(side, torch.is_grad_enabled() and any(p.requires_grad for p in params))
 
     def forward(self, features, focal):
         feats = list(features[:5])
@@ -446,6 +420,5 @@ class BtsModel(nn.Module):
         self.decoder = bts(params, self.encoder.feat_out_channels, params.bts_size)
 
     def forward(self, x, focal):
-        self.decoder.prepack()                   # optional (BTS_PREPACK=1): weight repack on a side stream under the encoder
         skip_feat = self.encoder(x)
         return self.decoder(skip_feat, focal)

@@ -133,14 +133,26 @@ def unpack_maps(gdst, gmaps, ds):
 # ---------------------------------------------------------------------------------------------
 # get_depth: 3x3 convolution to one channel + sigmoid * scale (csrc/conv_c1.hip)
 # ---------------------------------------------------------------------------------------------
-def conv_c1_supported(x):
-    return x.dim() == 4 and x.shape[3] <= 64 and (x.shape[3] // vec_of(x.dtype)) in (2, 4, 8, 16) \
+def conv_c1_supported(x, w=None):
+    """Domain of the streaming one-output-channel kernels.  w (f32 [1, Cin, 3, 3], PyTorch layout) must have exactly x's channel
+    count: the kernels read w[c * 9 + tap] for every channel of x, padding included."""
+    ok = x.dim() == 4 and x.shape[3] <= 64 and (x.shape[3] // vec_of(x.dtype)) in (2, 4, 8, 16) \
         and x.shape[3] % vec_of(x.dtype) == 0
+    if w is not None:
+        ok = ok and w.dim() == 4 and w.shape[0] == 1 and w.shape[1] == x.shape[3] and w.shape[2] == 3 and w.shape[3] == 3
+    return ok
+
+
+def _c1_check(x, w, what):
+    if not conv_c1_supported(x, w):
+        raise BtsAmdError("%s: x %s / w %s outside the streaming kernels' domain (w must be [1, C, 3, 3] with C = x's channel "
+                          "count, padding included)" % (what, tuple(x.shape), tuple(w.shape)))
 
 
 def conv3x3_c1_fwd(x, w, out_scale, out_scale_n=None):
     """x NHWC [N,H,W,C]; w f32 [1,C,3,3] (PyTorch layout) -> f32 map [N,H,W] = sigmoid(conv3x3) * out_scale * out_scale_n[n]."""
     _lib.require_gpu(x)
+    _c1_check(x, w, "conv3x3_c1_fwd")
     N, H, W, Cc = x.shape
     y = torch.empty((N, H, W), dtype=torch.float32, device=x.device)
     if profiler.ACTIVE is not None:
@@ -152,6 +164,7 @@ def conv3x3_c1_fwd(x, w, out_scale, out_scale_n=None):
 
 def conv3x3_c1_dgrad(grad_y, y, w, gx, accumulate, out_scale, out_scale_n=None, fold_elu_y=None):
     """gx (+)= data gradient of conv3x3_c1_fwd (sigmoid derivative included), optionally through the ELU of fold_elu_y."""
+    _c1_check(gx, w, "conv3x3_c1_dgrad")
     N, H, W, Cc = gx.shape
     if profiler.ACTIVE is not None:
         es = gx.element_size()
@@ -179,8 +192,15 @@ def conv3x3_c1_wgrad(grad_y, y, x, dwp, out_scale, out_scale_n=None):
 # ---------------------------------------------------------------------------------------------
 # silog
 # ---------------------------------------------------------------------------------------------
+def _aligned(t, nbytes):
+    """The silog kernels take 16-byte vectors of est / gt / grad and 4-byte words of the mask: an already-contiguous VIEW with an
+    odd storage offset (a sliced batch) is copied to a fresh allocation instead of being rejected by the launcher."""
+    return t if t is None or t.data_ptr() % nbytes == 0 else t.clone(memory_format=torch.contiguous_format)
+
+
 def silog_fwd(est, gt, mask, variance_focus, gt_threshold=0.0):
     _lib.require_gpu(est)
+    est, gt, mask = _aligned(est, 16), _aligned(gt, 16), _aligned(mask, 4)
     n = est.numel()
     ws = torch.empty(call("bts_silog_workspace_bytes", n) // 8, dtype=torch.float64, device=est.device)
     stats = torch.empty(3, dtype=torch.float64, device=est.device)
@@ -193,7 +213,8 @@ def silog_fwd(est, gt, mask, variance_focus, gt_threshold=0.0):
 
 
 def silog_bwd(est, gt, mask, variance_focus, stats, loss, grad_loss, gt_threshold=0.0):
-    g = torch.empty_like(est)
+    est, gt, mask = _aligned(est, 16), _aligned(gt, 16), _aligned(mask, 4)
+    g = torch.empty(est.shape, dtype=est.dtype, device=est.device)
     if profiler.ACTIVE is not None:
         profiler.note("silog_bwd", "hbm", est.numel() * (12 + (1 if mask is not None else 0)))
     call("bts_silog_bwd", _p(est), _p(gt), _p(mask), float(gt_threshold), est.numel(), float(variance_focus), _p(stats),

@@ -165,3 +165,40 @@ def broadcast_parameters(module, src=0, process_group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=process_group)
+
+
+class BufferSync:
+    """DDP's ``broadcast_buffers=True`` (the default the reference trains with, bts_main.py:352): at the START of every forward
+    pass rank 0's module buffers -- here the BatchNorm running_mean / running_var / num_batches_tracked of encoder and decoder --
+    overwrite every other rank's.  BatchNorm batch statistics stay rank-local (no SyncBN), but every rank evaluates
+    (`online_eval`, bts_main.py:250-304, runs `model.eval()` on all ranks) and checkpoints with RANK 0's running statistics.
+    `GradAllReducer` alone would leave them rank-local, so this is its companion:
+
+        sync = BufferSync(model)
+        for batch in loader:
+            sync()                      # before the forward pass, train or eval (what DDP.forward does)
+            ...
+
+    One broadcast per dtype: the buffers are packed into a flat tensor on the device, broadcast, and copied back (a few hundred
+    small tensors, ~0.5 M elements for DenseNet161-BTS -- one message instead of hundreds)."""
+
+    def __init__(self, module, src=0, process_group=None):
+        self.src, self.group = src, process_group
+        self.active = dist.is_initialized() and dist.get_world_size(process_group) > 1
+        by_dtype = {}
+        for b in module.buffers():
+            by_dtype.setdefault((b.dtype, b.device), []).append(b)
+        self.sets = list(by_dtype.values())
+
+    def __call__(self):
+        if not self.active:
+            return
+        with torch.no_grad():
+            for bufs in self.sets:
+                flat = torch.cat([b.reshape(-1) for b in bufs])
+                dist.broadcast(flat, src=self.src, group=self.group)
+                off = 0
+                for b in bufs:
+                    n = b.numel()
+                    b.copy_(flat[off:off + n].view_as(b))
+                    off += n

@@ -12,7 +12,7 @@ oracle is pinned against outputs of the reference module itself, generated in
 the build container by ``tools/make_golden.py`` and committed under
 ``tests/golden/`` (checked by ``tests/test_oracle_golden.py``), and, where
 ``/root/reference`` is present, against the live reference
-(``tests/test_oracle_vs_reference.py``).
+(``tests/test_oracle_golden.py::test_oracle_vs_live_reference_c1_plumbing``).
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this module.  Nothing under ``bts_amd/`` does.

@@ -3,7 +3,7 @@
 Works only where ``/root/reference`` exists (the build container); the GPU box
 has no reference tree, so nothing that runs there may call this.  Used by
 ``tools/make_golden.py`` (golden-vector generation) and by
-``tests/test_oracle_vs_reference.py`` (skipped when the tree is absent).
+``tests/test_oracle_golden.py::test_oracle_vs_live_reference_c1_plumbing`` (skipped when the tree is absent).
 
 Two shims are installed, neither edits the reference:
   * ``torch.Tensor.cuda -> identity`` when no GPU is visible, because

@@ -90,6 +90,25 @@ def test_silog_ragged_and_empty_mask():
     assert abs(got.item() - ref.item()) / ref.item() < 1e-5
 
 
+def test_silog_unaligned_views():
+    """est / gt / mask as already-contiguous views with an odd storage offset (a sliced batch with odd H*W): the vectorised
+    kernels need 16-byte aligned pointers, the wrappers copy instead of failing."""
+    from bts_amd.model import silog_loss
+    gen = torch.Generator().manual_seed(6)
+    est = torch.rand(3, 1, 7, 9, generator=gen) * 5 + 0.5
+    gt = torch.rand(3, 1, 7, 9, generator=gen) * 5 + 0.5
+    mask = torch.rand(3, 1, 7, 9, generator=gen) > 0.4
+    e, g, m = est.to(DEV)[1:].requires_grad_(True), gt.to(DEV)[1:], mask.to(DEV)[1:]
+    assert e.is_contiguous() and e.data_ptr() % 16 != 0
+    ec = est[1:].clone().requires_grad_(True)
+    ref = O.silog(ec, gt[1:], mask[1:], 0.85)
+    ref.backward()
+    got = silog_loss(0.85)(e, g, m)
+    got.backward()
+    assert abs(got.item() - ref.item()) / ref.item() < 1e-5
+    assert rel(e.grad.cpu(), ec.grad) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------------
 def _nhwc(x, dt, v):
     """NCHW f32 cpu -> NHWC device tensor with channels zero-padded to a multiple of v."""
@@ -115,6 +134,8 @@ CONV_CASES = [
     ("wg_halo_conv1like", 32, [32, 8], 9, 1, False, (8, 61, 125)),
     ("wg_halo_conv2like", 64, [64, 96, 8], 9, 1, False, (8, 61, 125)),
     ("wg_halo_1group", 24, [32], 9, 1, False, (8, 64, 128)),
+    ("wide96_dgrad", 128, [96, 64], 9, 1, False, (8, 61, 125)),   # data gradient towards a 96-channel skip: conv_halo_wide<3> (96-co tiles)
+    ("wide96_fwd", 192, [64, 72], 9, 1, False, (8, 61, 125)),    # 192 = 2 x 96 output channels: the forward on 96-co tiles
     ("wg_halo_wide_co", 136, [64, 40], 9, 1, False, (8, 61, 125)),  # > 64 output channels on a >= 256-tile map (3 ragged co tiles)
     ("wg_halo_up1like", 32, [64], 9, 1, True, (8, 61, 125)),      # conv_wgrad_halo_up, ragged
     ("wg_halo_up2like", 64, [128], 9, 1, True, (8, 64, 128)),     # 2 ci groups x 2 co groups
@@ -212,6 +233,7 @@ def test_conv3x3_c1_streaming_kernels(dt, shape):
     """get_depth's dedicated kernels (csrc/conv_c1.hip): sigmoid(conv3x3 to one channel) * scale[n], and the data gradient with the
     sigmoid derivative formed from (grad_y, y), written / accumulated / folded through an ELU output -- against torch autograd."""
     from bts_amd import ops
+    from bts_amd._lib import BtsAmdError
     N, Cc, H, W = shape
     gen = torch.Generator().manual_seed(N * 100 + Cc)
     v = 4 if dt == torch.float32 else 8
@@ -229,6 +251,9 @@ def test_conv3x3_c1_streaming_kernels(dt, shape):
     xd = _nhwc(x, dt, v)
     assert ops.conv_c1_supported(xd)
     wd, scd = w.to(DEV), sc_n.to(DEV)
+    assert ops.conv_c1_supported(xd, wd) and not ops.conv_c1_supported(xd, wd[:, :Cc - 1].contiguous())
+    with pytest.raises(BtsAmdError):         # the kernels index w by x's (padded) channel count: a narrower weight must not reach them
+        ops.conv3x3_c1_fwd(xd, wd[:, :Cc - 1].contiguous(), 80.0, scd)
     y = ops.conv3x3_c1_fwd(xd, wd, 80.0, scd)
     assert rel(y.unsqueeze(1), yr) < (1e-5 if dt == torch.float32 else 5e-3)
     gyd = gy.squeeze(1).to(DEV).contiguous()

@@ -97,6 +97,8 @@ def test_profiler_labels_follow_dispatch():
     assert conv._fwd_kernel(bf, 256, True, (8, 44, 152), 56) == "conv_halo_wide<bf16,128x256>"
     assert conv._fwd_kernel(bf, 128, True, (8, 88, 304), 29) == "conv_halo_wide<bf16,128x256>"
     assert conv._fwd_kernel(bf, 512, True, (8, 22, 76), 112) == "conv_igemm_dma<bf16,128x128>"
+    assert conv._fwd_kernel(bf, 96, True, (8, 176, 608), 8) == "conv_halo_wide<bf16,96x256>"     # conv2's data gradient towards the 96-channel skip
+    assert conv._fwd_kernel(bf, 192, True, (8, 44, 152), 32) == "conv_halo_wide<bf16,96x256>"    # conv4's, towards the 192-channel skip
     assert conv._fwd_kernel(torch.float32, 256, True, (8, 44, 152), 112) == "conv_igemm_dma<f32,128x128>"
     assert conv._fwd_kernel(bf, 32, True) == "conv_halo<bf16>"
     assert conv._fwd_kernel(bf, 64, True, (8, 176, 608), 21) == "conv_halo_wide<bf16,64x256>"      # conv2: 161 -> 64, three chunks

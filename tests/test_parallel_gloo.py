@@ -248,3 +248,73 @@ def test_grad_allreducer_one_shot_decoder_overlap_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def _buffer_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bts_amd.parallel import BufferSync, GradAllReducer, broadcast_parameters
+        torch.manual_seed(31 + rank)
+        net = Net()
+        broadcast_parameters(net)
+        ref = Net()
+        ref.load_state_dict(net.state_dict())
+        ddp = nn.parallel.DistributedDataParallel(ref, find_unused_parameters=True)      # broadcast_buffers=True: bts_main.py:352
+        red = GradAllReducer(net.parameters(), bucket_bytes=1 << 20)
+        sync = BufferSync(net)
+        opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=0.1)
+        opt_ref = torch.optim.SGD([p for p in ref.parameters() if p.requires_grad], lr=0.1)
+        gen = torch.Generator().manual_seed(1000 + rank)                                   # rank-local batches
+        for it in range(3):
+            x = torch.randn(2, 3, 8, 8, generator=gen) * (1.0 + rank)                      # different statistics per rank
+            red.zero_grad()
+            sync()
+            net(x).pow(2).mean().backward()
+            red.finish()
+            opt.step()
+            opt_ref.zero_grad()
+            ddp(x).pow(2).mean().backward()
+            opt_ref.step()
+            # after the step the running statistics are rank-local on BOTH sides (DDP broadcasts at the START of a forward)
+            for (n, b), (_, br) in zip(net.named_buffers(), ref.named_buffers()):
+                assert torch.allclose(b.float(), br.float(), rtol=1e-5, atol=1e-7), (it, n)
+        # online_eval (bts_main.py:250-304): model.eval() + forward on every rank -> every rank evaluates with rank 0's statistics
+        net.eval()
+        ddp.eval()
+        xe = torch.randn(1, 3, 8, 8, generator=torch.Generator().manual_seed(5))
+        sync()
+        with torch.no_grad():
+            ye, yr = net(xe), ddp(xe)
+        assert torch.allclose(ye, yr, rtol=1e-5, atol=1e-6)
+        flat = torch.cat([b.reshape(-1).float() for b in net.buffers()])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], g) for g in gathered), "buffers differ across ranks after BufferSync"
+        outs = [torch.zeros_like(ye) for _ in range(world)]
+        dist.all_gather(outs, ye)
+        assert all(torch.equal(outs[0], o) for o in outs), "eval outputs differ across ranks"
+        q.put((rank, "ok"))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_buffer_sync_matches_ddp_broadcast_buffers_world2_gloo():
+    """BatchNorm buffers under data parallelism: BufferSync() before each forward reproduces DistributedDataParallel's
+    broadcast_buffers=True (the reference's setting): identical buffers after every train step, and an eval forward that uses
+    rank 0's running statistics on every rank."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_buffer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res

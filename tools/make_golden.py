@@ -60,6 +60,7 @@ def gen_lpg(ref):
 def gen_reduction(ref):
     """reference reduction_1x1 fwd + bwd for the four head variants at bts_size=128/512."""
     g = torch.Generator().manual_seed(12)
+    torch.manual_seed(12)        # weights_init_xavier (bts.py:26-32) draws from the GLOBAL generator: seed it, or the file is not reproducible
     out = {}
     for tag, cin, cout, final, hw in (("r8_128", 32, 32, False, (4, 6)), ("r2_128", 16, 8, False, (6, 8)),
                                       ("r1_128", 8, 4, True, (8, 8)), ("r8_512", 128, 128, False, (3, 5)),
