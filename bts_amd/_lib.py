@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ("Hy", C.c_int32), ("Wy", C.c_int32), ("osc", C.c_int32), ("act", C.c_int32),
         ("out_scale", C.c_float), ("out_scale_n", C.c_void_p), ("accumulate", C.c_int32),
         ("fold_elu_y", C.c_void_p), ("fold_elu_stride", C.c_int32),
+        ("w2", C.c_void_p), ("y2", C.c_void_p), ("Cout2", C.c_int32), ("y2_stride", C.c_int32), ("accumulate2", C.c_int32),
     ]
 
 

@@ -65,64 +65,62 @@ def _cu_count():
     return _CUS[0]
 
 
+def _wide_mode():
+    """BTS_CONV_WIDE = 0 | 1 | 2: the one run-time switch of the forward dispatch (csrc/conv_igemm.hip::wide_mode): conv_halo_wide
+    off (counter-collection runs: rocprofv3 aborts on its 160 KiB of dynamic LDS) / by the fill heuristic [default] / wherever applicable."""
+    try:
+        return int(os.environ.get("BTS_CONV_WIDE", "1"))
+    except ValueError:
+        return 1
+
+
 def _wide_pays(cout, n, hg, wg):
     """Mirrors launch_halo_wide()'s fill heuristic (csrc/conv_halo_wide.hip)."""
     cus = _cu_count()
-    mode = os.environ.get("BTS_CONV_WIDE", "1")[:1]
-    if mode == "0":
+    mode = _wide_mode()
+    if mode == 0:
         return False
-    if mode == "2":
+    if mode >= 2:
         return True
-    bm = 128 if cout > 64 else 64
-    if cout > 64 and cout % 96 == 0 and cout % 128 != 0 and os.environ.get("BTS_WIDE_96", "1")[:1] != "0":
-        bm = 96
+    bm = 64 if cout <= 64 else (96 if cout % 96 == 0 and cout % 128 != 0 else 128)
     ntiles = _cdiv(wg, 32) * _cdiv(hg, 8) * n
     nco = _cdiv(cout, bm)
     wgs = ntiles * nco
     rounds = _cdiv(wgs, cus)
     fill = (hg * wg * n / (ntiles * 256.0)) * (cout / float(nco * bm)) * (wgs / float(rounds * cus))
-    return fill >= float(os.environ.get("BTS_WIDE_FILL", "0.60"))
-
-
-_CONV_BIG_DEFAULT = "t"      # launch_fwd()'s default schedule letter (csrc/conv_igemm.hip)
+    return fill >= 0.60
 
 
 def _fwd_kernel(dtype, cout, halo, geom=None, kv=8, up=False):
     """Name of the kernel launch_fwd() (csrc/conv_igemm.hip) picks: profiler label = rocprofv3 kernel family."""
-    if (halo and not up and dtype == torch.bfloat16 and 32 < cout <= 64 and kv > 8 and geom is not None
-            and os.environ.get("BTS_CONV_WIDE64", "1")[:1] != "0" and os.environ.get("BTS_CONV_WIDE", "1")[:1] != "0"
-            and _wide_pays(cout, *geom)):
+    bf = dtype == torch.bfloat16
+    if halo and not up and bf and 32 < cout <= 64 and kv > 8 and geom is not None and _wide_pays(cout, *geom):
         return "conv_halo_wide<bf16,64x256>"
     if halo and cout <= 64:
         return "conv_halo<%s>" % _dn(dtype)
-    if halo and not up and dtype == torch.bfloat16 and kv >= 8 and geom is not None and _wide_pays(cout, *geom):
-        if cout > 64 and cout % 96 == 0 and cout % 128 != 0 and os.environ.get("BTS_WIDE_96", "1")[:1] != "0":
+    if halo and not up and bf and kv >= 8 and geom is not None and _wide_pays(cout, *geom):
+        if cout % 96 == 0 and cout % 128 != 0:
             return "conv_halo_wide<bf16,96x256>"
         return "conv_halo_wide<bf16,128x256>"
-    if cout > 64 and geom is not None:
-        big = os.environ.get("BTS_CONV_BIG", _CONV_BIG_DEFAULT)[:1]
-        wgs = _cdiv(cout, 128) * _cdiv(geom[0] * geom[1] * geom[2], 256) * (4 if up else 1)
-        if big == "u" or (big == "w" and wgs >= int(os.environ.get("BTS_RING_MIN_WGS", "160"))):
-            return "conv_igemm_dma<%s,128x256,ring3>" % _dn(dtype)
     return "conv_igemm_dma<%s,%s>" % (_dn(dtype), "128x128" if cout > 64 else ("64x128" if cout > 32 else "32x256"))
 
 
 def _wgrad_kernel(dtype, cout, radius1, up, n, hg, wg, cols=None):
-    """Mirrors launch_wgrad() / launch_wgrad_tr().  cols = taps per phase x padded input channels (T * Ktot)."""
+    """Mirrors launch_wgrad() (csrc/conv_wgrad.hip) / launch_wgrad_tr() (csrc/conv_wgrad_tr.hip).  cols = taps per phase x padded
+    input channels (T * Ktot)."""
+    bf = dtype == torch.bfloat16
+    big_map = _cdiv(wg, 32) * _cdiv(hg, 8) * n >= 256
     if radius1 and not up and cout == 1:
         return "conv_wgrad_c1<%s>" % _dn(dtype)
-    if (radius1 and not up and 1 < cout <= int(os.environ.get("BTS_WGRAD_HALO_TR_MAXCOUT", "128")) and dtype == torch.bfloat16
-            and _cdiv(wg, 32) * _cdiv(hg, 8) * n >= int(os.environ.get("BTS_WGRAD_HALO_TR_MINTILES", "256"))
-            and os.environ.get("BTS_WGRAD_HALO_TR", "1")[:1] != "0"):
+    if radius1 and not up and 1 < cout <= 128 and bf and big_map:
         return "conv_wgrad_halo_tr<bf16>"
-    if 32 < cout <= 64 and dtype == torch.bfloat16 and os.environ.get("BTS_WGRAD_RING64", "1") != "0":
+    if 32 < cout <= 64 and bf:
         return "conv_wgrad_ring<bf16,64x256>"
-    if radius1 and cout <= 64 and dtype == torch.bfloat16 and _cdiv(wg, 32) * _cdiv(hg, 8) * n >= 256:
-        return "conv_wgrad_halo_up<bf16>" if up else "conv_wgrad_halo<bf16>"
-    if cout > 64 and dtype == torch.bfloat16 and os.environ.get("BTS_WGRAD_TR", "2")[:1] != "0":
-        mode = os.environ.get("BTS_WGRAD_TR", "2")[:1]
+    if radius1 and up and cout <= 64 and bf and big_map:
+        return "conv_wgrad_halo_up<bf16>"
+    if cout > 64 and bf:
         ring_tiles = _cdiv(cout, 128) * _cdiv(cols if cols is not None else 256, 256) * (4 if up else 1)
-        if mode == "3" or (mode != "1" and ring_tiles <= 2 * _cu_count()):
+        if ring_tiles <= 2 * _cu_count():
             return "conv_wgrad_ring<bf16,128x256>"
         return "conv_wgrad_tr<bf16,128x128>"
     return "conv_wgrad<%s,%s>" % (_dn(dtype), "128x128" if cout > 64 else ("64x128k2" if cout > 32 else "32x128k4"))
@@ -284,6 +282,44 @@ class ConvLayer:
                           2.0 * N * Hg * Wg * len(self.taps) * cseg * self.cout, "%s.dgrad%d" % (self.name, seg_index))
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return gx
+
+    def dual_dgrad_ok(self, dtype, i, j):
+        """Can the data gradients w.r.t. input segments i and j leave as ONE launch (bts_conv_desc_t::y2: second output formed from
+        the same dz fragments)?  Domain of conv_halo's register-weight form: bf16, radius-1 3x3, dz of <= 32 channels, segment i of
+        exactly 32 channels, segment j of <= 32 (padded) -- conv1 at bts_size 512: 32 -> 32 towards upconv1 and 32 -> 4 towards the
+        four depth maps."""
+        v = vec_of(dtype)
+        return (dtype == torch.bfloat16 and self.kk == 9 and self.dil == 1 and not self.up and pad_to(self.cout, v) <= 32
+                and self.seg_channels[i] == 32 and pad_to(self.seg_channels[j], v) <= 32)     # (main output: one full 32-channel block)
+
+    def dgrad_dual(self, dz, wd_i, i, gx_i, acc_i, fold_i, wd_j, j, gx_j, acc_j):
+        """gx_i (+)= dgrad w.r.t. segment i (optionally through fold_i's ELU), gx_j (+)= dgrad w.r.t. segment j: one pass over dz."""
+        dtype = dz.dtype
+        N, Hg, Wg = gx_i.shape[0], gx_i.shape[1], gx_i.shape[2]
+        d = self._desc(dtype, [dz], N, Hg, Wg)
+        d.isc, d.nphase, d.T = 1, 1, self.T
+        for t, (dy, dx, a, b) in enumerate(self.taps):
+            d.dy[t], d.dx[t], d.ioy[t], d.iox[t] = -dy, -dx, 0, 0
+        d.w = wd_i.data_ptr()
+        d.Cout = gx_i.shape[3]
+        self._set_out(d, gx_i)
+        d.osc = 1
+        d.act = _lib.ACT_NONE
+        d.out_scale = 1.0
+        d.out_scale_n = None
+        d.accumulate = int(acc_i)
+        if fold_i is not None:
+            if fold_i.shape != gx_i.shape or fold_i.dtype != gx_i.dtype:
+                raise _lib.BtsAmdError("dgrad_dual: fold_elu_y must have the gradient's shape and dtype")
+            d.fold_elu_y, d.fold_elu_stride = fold_i.data_ptr(), pix_stride(fold_i)
+        if gx_j.shape[:3] != gx_i.shape[:3] or gx_j.dtype != gx_i.dtype:
+            raise _lib.BtsAmdError("dgrad_dual: the two gradients must share pixels and dtype")
+        d.w2, d.y2, d.Cout2, d.y2_stride, d.accumulate2 = wd_j.data_ptr(), gx_j.data_ptr(), gx_j.shape[3], pix_stride(gx_j), int(acc_j)
+        if profiler.ACTIVE is not None:
+            profiler.note("conv_halo<%s>" % _dn(dtype), "mfma",
+                          2.0 * N * Hg * Wg * len(self.taps) * (self.seg_channels[i] + self.seg_channels[j]) * self.cout,
+                          "%s.dgrad%d+%d" % (self.name, i, j))
+        call("bts_conv_fwd", C.byref(d), stream_ptr())
 
     def wgrad_packed(self, segs, dz, dwp):
         """Accumulates the packed f32 weight gradient [Cout, nphase*T, Ktot] into `dwp` (caller-zeroed)."""

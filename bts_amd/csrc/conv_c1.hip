@@ -406,6 +406,7 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
     }
 }
 
+
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 }  // namespace
@@ -417,9 +418,8 @@ extern "C" int bts_conv3x3_c1_fwd(const void* x, int dtype, int x_stride, int C,
     BTS_CHECK_ARG(C > 0 && C % V == 0 && x_stride >= C && x_stride % V == 0 && ((uintptr_t)x & 15) == 0);
     if (C * ES > 256) return BTS_ERR_UNSUPPORTED;                      // wider inputs: the MFMA path (bts_conv_fwd)
     hipStream_t st = (hipStream_t)stream;
-    // BTS_C1_FWD=1: the first form (LDS patch, thread = output pixel) for A/B; default: the second form where its domain allows
-    static const int form = [] { const char* e = getenv("BTS_C1_FWD"); return e ? atoi(e) : 2; }();
-    if (form >= 2 && pow2(C / V) && C / V <= 16 && C <= 64) {
+    // the input-major form where its domain allows, else the first form (LDS patch, thread = output pixel)
+    if (pow2(C / V) && C / V <= 16 && C <= 64) {
         // 16 x 64 tiles, 45 KiB of LDS (3 workgroups per CU).  8 x 64 (24 KiB, 6 per CU) and 2 / 4 loads in flight per thread measured
         // the same within 2 % (gpurun r03ad: 76-81 us bf16): the kernel is bound by its ~125 VALU operations per input vector.
         constexpr int TH = 16, TW = 64;
@@ -487,8 +487,7 @@ extern "C" int bts_conv3x3_c1_wgrad(const float* grad_y, const float* y, const v
     const int CV = C / V;
     if (!pow2(CV) || CV > 16 || C > 64) return BTS_ERR_UNSUPPORTED;
     const long tiles = (long)N * ((H + 7) / 8) * ((W + 63) / 64);
-    static const int per_cu_env = [] { const char* e = getenv("BTS_C1_WGRAD_PERCU"); return e ? atoi(e) : 0; }();   // A/B knob
-    const long per_cu = per_cu_env > 0 ? per_cu_env : dtype == BTS_F32 ? 4 : 3;         // 110 / 164 VGPRs: waves per SIMD
+    const long per_cu = dtype == BTS_F32 ? 4 : 3;         // 110 / 164 VGPRs: waves per SIMD
     const long wgs = tiles < per_cu * bts_cu_count() ? tiles : per_cu * bts_cu_count();
     hipStream_t st = (hipStream_t)stream;
     if (dtype == BTS_F32)

@@ -49,6 +49,10 @@ struct ConvK {
     const char* fold_y;            // data-gradient: multiply the stored value by ELU'(fold_y[pixel][co]) (ELU output), or nullptr
     int fold_stride;               // pixel stride of fold_y in elements (dtype = y's)
     int n_px_tiles, n_co_tiles;
+    // second output of a data-gradient launch (bts_conv_desc_t::y2), conv_halo only
+    const char* w2;
+    char* y2;
+    int Cout2, y2_stride, accumulate2;
     // wgrad only
     const char* dz;
     int dz_stride;
@@ -56,7 +60,6 @@ struct ConvK {
     int n_col_tiles, nchunks, chunks_per_split;
     int halo_ok;   // every tap within radius 1 on an unscaled same-size input: eligible for conv_halo
     int kmajor;    // conv_igemm_dma K order: 1 = channel chunk outer, taps inner (needs KV % 8 == 0); 0 = tap outer
-    int halo_regw; // conv_halo, one-chunk 9-tap layers with <= 3 k-steps: weight fragments live in registers (BTS_HALO_REGW=0: A/B)
 };
 
 // The strength-reduced address paths multiply (pixel index) x (pixel stride in bytes) in 32 bits: a launcher that uses them
@@ -418,9 +421,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16_t (&acc)[TM
     }
 }
 
-// conv_igemm_pp.hip: forward / data-gradient of the wide bf16 layers with two staggered wave groups per workgroup; returns
-// BTS_ERR_UNSUPPORTED outside its domain (the caller then uses conv_igemm_dma).
-int launch_fwd_pp(const ConvK& k, hipStream_t st, int variant);
+// conv_halo.hip: radius-1 3x3 / sub-pixel up-convolution forward and data-gradient with <= 64 output channels on 2-D pixel tiles with
+// an LDS halo (f32 selects the f32 instantiations); BTS_ERR_UNSUPPORTED outside its domain.
+int launch_halo(const ConvK& k, hipStream_t st, bool f32);
 
 // conv_halo_wide.hip: 3x3 radius-1 forward / data-gradient with > 64 output channels on 2-D pixel tiles (patch staged once
 // per channel chunk, weights streamed per tap); BTS_ERR_UNSUPPORTED outside its domain.
@@ -436,5 +439,69 @@ int launch_wgrad_ring64(const ConvK& k, hipStream_t st);
 // conv_wgrad_tr.hip: bf16 weight gradient of the wide layers (LDS-DMA staging + transpose reads); returns BTS_ERR_UNSUPPORTED
 // when the shape is outside its domain (the caller then falls back to conv_wgrad).
 int launch_wgrad_tr(const ConvK& k, hipStream_t st);
+
+// host side: bts_conv_desc_t -> the fields of ConvK every launcher needs (forward / data-gradient and weight-gradient entry points)
+static inline int fill_common(const bts_conv_desc_t* d, ConvK& k) {
+    BTS_CHECK_ARG(d != nullptr);
+    BTS_CHECK_ARG(d->dtype == BTS_F32 || d->dtype == BTS_BF16);
+    const int VEC = d->dtype == BTS_F32 ? 4 : 8;
+    BTS_CHECK_ARG(d->N > 0 && d->Hg > 0 && d->Wg > 0 && d->Hx > 0 && d->Wx > 0);
+    BTS_CHECK_ARG(d->nseg >= 1 && d->nseg <= BTS_MAX_SEG);
+    BTS_CHECK_ARG(d->nphase == 1 || d->nphase == 4);
+    BTS_CHECK_ARG(d->T >= 1 && d->nphase * d->T <= BTS_MAX_TAP);
+    BTS_CHECK_ARG(d->isc >= 1 && d->isc <= 2 && d->osc >= 1 && d->osc <= 2);
+    BTS_CHECK_ARG(d->Cout >= 1);
+    BTS_CHECK_ARG((long)d->N * d->Hg * d->Wg < (1l << 31));
+    int cum = 0;
+    for (int s = 0; s < BTS_MAX_SEG; ++s) {
+        k.seg_cum[s] = cum;
+        if (s < d->nseg) {
+            BTS_CHECK_ARG(d->seg[s].ptr != nullptr && d->seg[s].C > 0 && d->seg[s].C % VEC == 0);
+            BTS_CHECK_ARG(d->seg[s].stride >= d->seg[s].C && d->seg[s].stride % VEC == 0);
+            BTS_CHECK_ARG(((uintptr_t)d->seg[s].ptr & 15) == 0);
+            k.seg_ptr[s] = (const char*)d->seg[s].ptr;
+            k.seg_stride[s] = d->seg[s].stride;
+            cum += d->seg[s].C / VEC;
+        } else {
+            k.seg_ptr[s] = nullptr;
+            k.seg_stride[s] = 0;
+        }
+    }
+    k.seg_cum[BTS_MAX_SEG] = cum;
+    k.nseg = d->nseg;
+    k.KV = cum;
+    k.Ktot = cum * VEC;
+    k.N = d->N; k.Hg = d->Hg; k.Wg = d->Wg; k.M = d->N * d->Hg * d->Wg;
+    k.fd_w = make_fastdiv(d->Wg);
+    k.fd_hw = make_fastdiv(d->Hg * d->Wg);
+    k.Hx = d->Hx; k.Wx = d->Wx; k.isc = d->isc;
+    k.T = d->T; k.nphase = d->nphase; k.Ttot = d->nphase * d->T;
+    for (int t = 0; t < BTS_MAX_TAP; ++t) {
+        uint32_t v = 0;
+        if (t < k.Ttot) {
+            BTS_CHECK_ARG(d->dy[t] >= -127 && d->dy[t] <= 127 && d->dx[t] >= -127 && d->dx[t] <= 127);
+            BTS_CHECK_ARG(d->ioy[t] >= 0 && d->ioy[t] < 16 && d->iox[t] >= 0 && d->iox[t] < 16);
+            v = (uint32_t)(uint8_t)(int8_t)d->dy[t] | ((uint32_t)(uint8_t)(int8_t)d->dx[t] << 8) |
+                ((uint32_t)d->ioy[t] << 16) | ((uint32_t)d->iox[t] << 20);
+        }
+        k.taps[t] = v;
+        k.tapoff[t] = t < k.Ttot ? (d->dy[t] * d->isc + d->ioy[t]) * d->Wx + d->dx[t] * d->isc + d->iox[t] : 0;
+    }
+    {   // kernels use 32-bit byte offsets inside a tensor
+        const long es = d->dtype == BTS_F32 ? 4 : 2;
+        for (int s = 0; s < d->nseg; ++s) {
+            k.seg_sb[s] = (uint32_t)(d->seg[s].stride * es);
+            if ((long)d->N * d->Hx * d->Wx * d->seg[s].stride * es >= (1l << 32)) return BTS_ERR_UNSUPPORTED;
+        }
+    }
+    k.Cout = d->Cout;
+    k.Hy = d->Hy; k.Wy = d->Wy; k.osc = d->osc;
+    k.halo_ok = d->isc == 1 && d->Hx == d->Hg && d->Wx == d->Wg &&
+                ((d->nphase == 1 && d->T == 9 && d->osc == 1) || (d->nphase == 4 && d->T == 4 && d->osc == 2));
+    for (int t = 0; t < k.Ttot && k.halo_ok; ++t)
+        if (d->dy[t] < -1 || d->dy[t] > 1 || d->dx[t] < -1 || d->dx[t] > 1 || d->ioy[t] != 0 || d->iox[t] != 0) k.halo_ok = 0;
+    return BTS_OK;
+}
+
 
 }  // namespace bts_conv

@@ -52,7 +52,10 @@ __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
     constexpr int BM = NCO * 32;                                       // output channels per workgroup
     constexpr int WPASS = (BM + RP - 1) / RP;                          // weight pieces per thread per tap (2 / 1); NCO = 3: the second
     constexpr int WBYTES = WPASS * RP * 128;                           // piece is half zero page (rows 96..127 of the stage are never read)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (static LDS.  rocprofv3 aborts every --pmc pass at this kernel's first dispatch -- HSA_STATUS_ERROR_INVALID_PACKET_FORMAT,
+    // profiles/r03_pmc_fetch_abort_with_halo_wide.log -- whether the 160 KiB are static or dynamic and whether or not the kernel is
+    // excluded from collection by --kernel-exclude-regex (gpurun r04c / r04d): counter passes run with BTS_CONV_WIDE=0)
+    __shared__ __attribute__((aligned(16))) char smem[wide_lds_bytes<NCO>()];
     char* sPatch = smem;
     char* sWring = smem + 2 * PBYTES;
 
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
 
 template <int NCO>
 static int launch_halo_wide_n(ConvK& k, hipStream_t st, int force) {
-    constexpr int BM = NCO * 32, LDS_BYTES = wide_lds_bytes<NCO>();
+    constexpr int BM = NCO * 32;
     k.n_co_tiles = ceil_div(k.Cout, BM);
     const int ntiles = ceil_div(k.Wg, TW) * ceil_div(k.Hg, TH) * k.N;
     if (!force) {
@@ -318,23 +321,16 @@ static int launch_halo_wide_n(ConvK& k, hipStream_t st, int force) {
                             ((double)wgs / ((double)rounds * cus));
         // Round 3 (gpurun r03k, after the 16-byte epilogue stores): the four data-gradients at fill 0.60-0.70 (conv2 / conv3 / conv4 /
         // conv5 towards their encoder skips: 96 / 96 / 192 / 384 channels = 0.75 of their co tiles) measured 212 -> 194, 105 -> 84,
-        // 95 -> 77 and 77 -> 69 us against conv_igemm_dma, so the threshold is 0.60.  BTS_WIDE_FILL overrides it (A/B).
-        static const double min_fill = [] { const char* e = getenv("BTS_WIDE_FILL"); return e ? atof(e) : 0.60; }();
-        if (fill < min_fill) return BTS_ERR_UNSUPPORTED;
+        // 95 -> 77 and 77 -> 69 us against conv_igemm_dma, so the threshold is 0.60.
+        if (fill < 0.60) return BTS_ERR_UNSUPPORTED;
     }
-    static const int epi_on = [] { const char* e = getenv("BTS_WIDE_EPI"); return (e && e[0] == '0') ? 0 : 1; }();
     int epi = 0;
-    if (epi_on && k.vec_store && k.wide_store && !k.y_f32 && k.Cout % 32 == 0 && k.out_scale == 1.f && !k.out_scale_n) {
+    if (k.vec_store && k.wide_store && !k.y_f32 && k.Cout % 32 == 0 && k.out_scale == 1.f && !k.out_scale_n) {
         if (k.act == BTS_ACT_ELU && !k.accumulate && !k.fold_y) epi = 1;
         else if (k.act == BTS_ACT_NONE && (k.accumulate || k.fold_y)) epi = k.accumulate ? (k.fold_y ? 4 : 2) : 3;
     }
-    static DynLdsCache lds_set[5];
     const dim3 grid((unsigned)(ntiles * k.n_co_tiles));
-#define BTS_WIDE_(E)                                                                                                       \
-    do {                                                                                                                   \
-        if (ensure_dyn_lds((const void*)conv_halo_wide<NCO, E>, LDS_BYTES, lds_set[E]) != BTS_OK) return BTS_ERR_LAUNCH;   \
-        hipLaunchKernelGGL((conv_halo_wide<NCO, E>), grid, dim3(NTHR), (size_t)LDS_BYTES, st, k);                          \
-    } while (0)
+#define BTS_WIDE_(E) hipLaunchKernelGGL((conv_halo_wide<NCO, E>), grid, dim3(NTHR), 0, st, k)
     if (epi == 1) BTS_WIDE_(1);
     else if (epi == 2) BTS_WIDE_(2);
     else if (epi == 3) BTS_WIDE_(3);
@@ -351,9 +347,8 @@ int launch_halo_wide(const ConvK& k0, hipStream_t st, int force) {
     if (!segs_fit_u32(k)) return BTS_ERR_UNSUPPORTED;                  // ppix * sb is a 32-bit product in the kernel
     if (k.Cout <= 64) return launch_halo_wide_n<2>(k, st, force);
     // 96-channel tiles where they divide the output exactly and 128-channel tiles do not (DenseNet161's 96 / 192-channel skips:
-    // 0.75 of a 128-channel tile's MFMAs and fragment reads); BTS_WIDE_96=0: A/B
-    static const int w96_on = [] { const char* e = getenv("BTS_WIDE_96"); return (e && e[0] == '0') ? 0 : 1; }();
-    if (w96_on && k.Cout % 96 == 0 && k.Cout % 128 != 0) return launch_halo_wide_n<3>(k, st, force);
+    // 0.75 of a 128-channel tile's MFMAs and fragment reads; same-box A/B, profiles/r04_patches_ab_*: conv2 179 -> 156 us, conv4 72 -> 63)
+    if (k.Cout % 96 == 0 && k.Cout % 128 != 0) return launch_halo_wide_n<3>(k, st, force);
     return launch_halo_wide_n<4>(k, st, force);
 }
 

@@ -654,22 +654,19 @@ int launch_wgrad_tr(const ConvK& k0, hipStream_t st) {
     if (k.Cout <= 64) return BTS_ERR_UNSUPPORTED;
     if ((long)k.N * k.Hy * k.Wy * k.dz_stride * 2 >= (1l << 32) || !segs_fit_u32(k)) return BTS_ERR_UNSUPPORTED;   // 32-bit byte offsets
     k.nchunks = ceil_div(k.M, KC);
-    // BTS_WGRAD_TR: 1 = the two-stage 128 x 128 kernel of round 2 everywhere (A/B); 2 = the 128 x 256 three-stage ring where it
-    // pays [default]; 3 = the ring everywhere (A/B)
-    static const int mode = [] { const char* e = getenv("BTS_WGRAD_TR"); return e ? atoi(e) : 2; }();
+    // the 128 x 256 three-stage ring where it pays, the two-stage 128 x 128 kernel of round 2 elsewhere:
     // Measured per layer on one box (gpurun r03c, kernel alone, two-stage 128 x 128 -> ring 128 x 256, TFLOP/s): conv5 771 -> 768,
     // conv4 726 -> 774, daspp_conv 766 -> 766, conv3 556 -> 589, upconv3 383 -> 478, upconv4 636 -> 633, dilated 3x3 508 -> 496,
     // ASPP 1x1 380 -> 384, upconv5 665 -> 616: the ring wins where the pixel split is deep (few tiles, long K per workgroup) and
     // loses where the tiles alone exceed two rounds of the chip (upconv5: 560 ring tiles) -- those keep the 128 x 128 form.
     const long ring_tiles = (long)ceil_div(k.Cout, 128) * ceil_div((long)k.T * k.Ktot, 256) * k.nphase;
-    if (mode >= 2 && (mode >= 3 || ring_tiles <= 2l * bts_cu_count())) {
+    if (ring_tiles <= 2l * bts_cu_count()) {
         constexpr int NST = 3, LDS = NST * 6 * SUB;
         k.n_co_tiles = ceil_div(k.Cout, 128);
         k.n_col_tiles = ceil_div((long)k.T * k.Ktot, 256);
         const int tiles = k.n_co_tiles * k.n_col_tiles * k.nphase;
         // one 144 KiB workgroup per CU; split over pixels only until the chip is full, >= 8 chunks per workgroup
-        static const int slots_env = [] { const char* e = getenv("BTS_WGRAD_RING_WGS"); return e ? atoi(e) : 0; }();
-        const int slots = slots_env > 0 ? slots_env : bts_cu_count();
+        const int slots = bts_cu_count();
         int splits = slots / tiles;
         if (splits > k.nchunks / 8) splits = k.nchunks / 8;
         if (splits < 1) splits = 1;
@@ -688,8 +685,8 @@ int launch_wgrad_tr(const ConvK& k0, hipStream_t st) {
     // Pixel split: only until the chip is full -- `slots` workgroups at a time (2 per CU: 64 KiB of LDS each).  conv5: 252
     // tiles -> 2 splits (one round of 105 chunks); layers with more tiles than slots are not split at all: a wave-quantisation
     // model that split upconv5 (1104 tiles) 3-way to even out its rounds measured 269 us against 250 us unsplit (r02l) -- the
-    // 212 MB of extra f32 atomics cost more than the idle tail.  BTS_WGRAD_TR_WGS overrides slots (A/B).
-    static const int slots = [] { const char* e = getenv("BTS_WGRAD_TR_WGS"); return e ? atoi(e) : 512; }();
+    // 212 MB of extra f32 atomics cost more than the idle tail.
+    const int slots = 512;
     int splits = slots / tiles;
     if (splits > k.nchunks / 4) splits = k.nchunks / 4;          // >= 4 chunks per workgroup
     if (splits < 1) splits = 1;

@@ -264,11 +264,20 @@ class DecoderRun:
                     dz = y.g
                 else:
                     dz = ops.act_bwd(y.g, y.t, act, out=y.g)
-                for i, s in enumerate(segs):
-                    acc = s.g is not None
-                    if not acc:
+                accs = []
+                for s in segs:
+                    accs.append(s.g is not None)
+                    if s.g is None:
                         s.g = torch.empty(s.t.shape, dtype=self.dtype, device=dev)
-                    L.dgrad(dz, self.packs.dgrad[(name, i)], i, s.g, acc, s.t if folds[i] else None)
+                done = set()
+                if len(segs) == 2 and not folds[1] and L.dual_dgrad_ok(dz.dtype, 0, 1):
+                    # both data gradients from one pass over dz (conv1: towards upconv1 and towards the depth-map slots)
+                    L.dgrad_dual(dz, self.packs.dgrad[(name, 0)], 0, segs[0].g, accs[0], segs[0].t if folds[0] else None,
+                                 self.packs.dgrad[(name, 1)], 1, segs[1].g, accs[1])
+                    done = {0, 1}
+                for i, s in enumerate(segs):
+                    if i not in done:
+                        L.dgrad(dz, self.packs.dgrad[(name, i)], i, s.g, accs[i], s.t if folds[i] else None)
                     if folds[i]:
                         s.g_is_dz = True
                 off, shape = self.packs.dwp_off[name]
@@ -299,6 +308,8 @@ class DecoderRun:
                 if fold:
                     x.g_is_dz = True
                 off, shape = self.packs.dwp_off[name]
+                # (one fused pass over x for both gradients was built and measured in round 4: 227 us against 110 + 106 -- its 144
+                # accumulators + weights per lane leave two waves per SIMD; removed)
                 ops.conv3x3_c1_wgrad(y.g, y.t, x.t, self.dwp_arena[off:off + shape[0] * shape[1] * shape[2]].view(shape),
                                      out_scale, out_scale_n)
             self.tape.append(bwd)

@@ -199,6 +199,16 @@ typedef struct {
      * pixel stride fold_elu_stride. */
     const void* fold_elu_y;
     int32_t fold_elu_stride;
+    /* Second output of a data-gradient launch (optional: y2 != NULL).  A convolution over a concatenation has one data gradient per
+     * input tensor, all formed from the same dz; this launch then also writes the gradient w.r.t. ANOTHER input segment in the same
+     * pass over dz:   y2[pixel][c2] (+)= sum_{t,k} w2[c2][t][k] * x[pixel + t][k]      (x = `seg`, i.e. dz)
+     * w2 is packed like w ([Cout2][nphase*T][Ktot]), y2 has y's dtype, spatial size and coordinate scale, pixel stride y2_stride,
+     * Cout2 % 4 == 0; no activation, scale or fold on it.  Domain: bf16, radius-1 3x3, Ktot <= 32, Cout <= 32, Cout2 <= 32
+     * (conv1's two data gradients, bts.py:183-184, 260-261: 32 -> 32 channels towards upconv1 and 32 -> 4 towards the depth maps);
+     * BTS_ERR_UNSUPPORTED outside it -- issue two launches. */
+    const void* w2;
+    void* y2;
+    int32_t Cout2, y2_stride, accumulate2;
 } bts_conv_desc_t;
 
 int bts_conv_fwd(const bts_conv_desc_t* d, bts_stream_t stream);

@@ -281,6 +281,47 @@ def test_conv3x3_c1_streaming_kernels(dt, shape):
     assert (dwp[0, :, Cc:] == 0.5).all()                                # the padding columns are not touched
 
 
+@pytest.mark.parametrize("shape", [(2, 21, 70), (8, 61, 125)], ids=["small", "multi_tile"])
+@pytest.mark.parametrize("mode", ["plain", "acc_fold"])
+def test_conv_dual_data_gradient(shape, mode):
+    """conv1-like layer (32 + 4 -> 32 channels, bf16): the data gradients towards both input tensors from ONE launch
+    (bts_conv_desc_t::y2) against F.conv2d autograd and against the two single launches (bit-identical: same MFMA order)."""
+    from bts_amd.conv import ConvLayer
+    N, H, W = shape
+    dt, v = torch.bfloat16, 8
+    gen = torch.Generator().manual_seed(N * 1000 + W)
+    cout, segc = 32, [32, 4]
+    w = torch.randn(cout, sum(segc), 3, 3, generator=gen) * (1.0 / (36 * 9) ** 0.5)
+    wq = w.to(dt).float()
+    xs = [torch.randn(N, c, H, W, generator=gen).to(dt).float().requires_grad_(True) for c in segc]
+    dz = torch.randn(N, cout, H, W, generator=gen).to(dt).float()
+    F.conv2d(torch.cat(xs, 1), wq, padding=1).backward(dz)
+    L = ConvLayer("c1like", cout, segc, 9)
+    assert L.dual_dgrad_ok(dt, 0, 1)
+    wd = [L.pack_dgrad(w.to(DEV), dt, i) for i in range(2)]
+    dzd = _nhwc(dz, dt, v)
+    fold = _nhwc(torch.randn(N, 32, H, W, generator=gen), dt, v) if mode == "acc_fold" else None
+    base0 = _nhwc(torch.randn(N, 32, H, W, generator=gen), dt, v)
+    base1 = _nhwc(torch.randn(N, 4, H, W, generator=gen), dt, v)
+    acc = mode == "acc_fold"
+    g0 = base0.clone() if acc else torch.full_like(base0, float("nan"))
+    g1 = base1.clone() if acc else torch.full_like(base1, float("nan"))
+    L.dgrad_dual(dzd, wd[0], 0, g0, acc, fold, wd[1], 1, g1, acc)
+    r0 = base0.clone() if acc else torch.full_like(base0, float("nan"))
+    r1 = base1.clone() if acc else torch.full_like(base1, float("nan"))
+    L.dgrad(dzd, wd[0], 0, r0, acc, fold)
+    L.dgrad(dzd, wd[1], 1, r1, acc)
+    assert torch.equal(g0, r0) and torch.equal(g1, r1)
+    want0, want1 = xs[0].grad, xs[1].grad
+    if acc:
+        fac = torch.where(fold.float() > 0, torch.ones_like(fold, dtype=torch.float32), fold.float() + 1.0).permute(0, 3, 1, 2).cpu()
+        want0 = (want0 + base0.float().permute(0, 3, 1, 2).cpu()) * fac
+        want1 = want1 + base1.float().permute(0, 3, 1, 2).cpu()[:, :4]
+    assert rel(g0.float().permute(0, 3, 1, 2), want0) < 2e-2
+    assert rel(g1.float().permute(0, 3, 1, 2)[:, :4], want1) < 2e-2
+    assert g1[..., 4:].float().abs().max().item() == (base1[..., 4:].float().abs().max().item() if acc else 0.0)
+
+
 def test_conv_epilogues():
     """ELU / sigmoid*scale_n epilogues and the single-channel f32 map output."""
     from bts_amd.conv import ConvLayer

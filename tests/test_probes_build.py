@@ -28,3 +28,19 @@ def test_probe_compiles_against_product_source(tmp_path, probe):
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert out.exists() and out.stat().st_size > 0
+
+
+@pytest.mark.parametrize("src", ["conv_legacy.hip", "conv_igemm_pp.hip"])
+def test_archived_kernel_variants_still_compile(tmp_path, src):
+    """tools/probes/legacy/: convolution schedules that were measured and lost (register staging, whole-chunk prefetch, the
+    three-stage ring, two staggered wave groups, the 2-byte-scatter weight gradient) are out of libbts_amd.so but keep compiling
+    against csrc/conv_common.h, so an A/B can be repeated."""
+    hipcc = _hipcc()
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    out = tmp_path / src.replace(".hip", ".o")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-c",
+           os.path.join(ROOT, "tools", "probes", "legacy", src), "-o", str(out)]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out.exists() and out.stat().st_size > 0

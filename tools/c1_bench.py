@@ -1,6 +1,6 @@
 """Event-timed get_depth kernels (csrc/conv_c1.hip) at the bench shape: forward, data gradient, weight gradient.
 
-    python tools/c1_bench.py [--n 8 --h 352 --w 1216 --c 32 --dtype bf16]        (BTS_C1_FWD=1|2 selects the forward form)
+    python tools/c1_bench.py [--n 8 --h 352 --w 1216 --c 32 --dtype bf16]
 
 Prints one JSON line per kernel: average microseconds over `--iters` back-to-back launches and the algorithmic GB/s.
 """
@@ -52,12 +52,13 @@ def main():
         ("conv_c1_fwd", lambda: ops.conv3x3_c1_fwd(x, w, 80.0, sc), px * (a.c * es + 4)),
         ("conv_c1_dgrad", lambda: ops.conv3x3_c1_dgrad(gy, y, w, gx, False, 80.0, sc), px * (8 + a.c * es)),
         ("conv_c1_dgrad+acc+fold", lambda: ops.conv3x3_c1_dgrad(gy, y, w, gx, True, 80.0, sc, x), px * (8 + 3 * a.c * es)),
+        ("conv_c1_dgrad+fold", lambda: ops.conv3x3_c1_dgrad(gy, y, w, gx, False, 80.0, sc, x), px * (8 + 2 * a.c * es)),
         ("conv_c1_wgrad", lambda: ops.conv3x3_c1_wgrad(gy, y, x, dwp, 80.0, sc), px * (8 + a.c * es)),
     ]
     for name, fn, nbytes in rows:
         us = timed(fn, a.iters)
         print(json.dumps({"kernel": name, "shape": [a.n, a.h, a.w, a.c], "dtype": a.dtype, "us": round(us, 2),
-                          "alg_GBps": round(nbytes / us * 1e-3, 1), "form": os.environ.get("BTS_C1_FWD", "2")}), flush=True)
+                          "alg_GBps": round(nbytes / us * 1e-3, 1)}), flush=True)
 
 
 if __name__ == "__main__":

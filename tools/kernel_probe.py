@@ -216,7 +216,7 @@ def main():
         res += conv_case("conv2", bf, 64, [64, 96, 1], 9, 1, False, B, 176, 608, a.iters, ("fwd",))
         res += conv_case("upconv1", bf, 32, [64], 9, 1, True, B, 176, 608, a.iters, ("fwd",))
         res += conv_case("conv1", bf, 32, [32, 4], 9, 1, False, B, 352, 1216, a.iters, ("fwd",))
-    if a.set == "mid":      # layers whose 128x256 tiling gives < 2 workgroups per CU (A/B target for BTS_CONV_BIG=a|d)
+    if a.set == "mid":      # layers whose 128x256 tiling gives < 2 workgroups per CU
         B = 8
         res += conv_case("daspp3x3", bf, 128, [256], 9, 6, False, B, 44, 152, a.iters, ("fwd", "dgrad"))
         res += conv_case("daspp1x1_24", bf, 256, [256, 192, 128, 128, 128, 128], 1, 1, False, B, 44, 152, a.iters, ("fwd", "dgrad"))
@@ -235,7 +235,7 @@ def main():
         res += conv_case("conv1", bf, 32, [32, 4], 9, 1, False, B, 352, 1216, a.iters, ("fwd", "wgrad"))
         res += conv_case("get_depth", bf, 1, [32], 9, 1, False, B, 352, 1216, a.iters, ("wgrad",))
         res += chain_cases(8, 352, 1216, bf, a.iters)
-    if a.set == "wgrad":    # wide-layer weight gradients, kernel alone (A/B: BTS_WGRAD_TR=0|1 in separate processes)
+    if a.set == "wgrad":    # wide-layer weight gradients, kernel alone
         B = 8
         res += conv_case("conv5", bf, 512, [512, 384], 9, 1, False, B, 22, 76, a.iters, ("wgradk",))
         res += conv_case("upconv5", bf, 512, [2208], 9, 1, True, B, 11, 38, a.iters, ("wgradk",))

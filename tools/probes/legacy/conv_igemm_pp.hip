@@ -24,7 +24,7 @@
 //   WAR  every LOAD section ends with lgkmcnt(0) before its barrier, and a stage is re-filled only by DMA issued at least one
 //        barrier after the last LOAD section that read it (3 stages / chunk-long sections, or 2 stages / half-chunk sections:
 //        the arithmetic is spelled out at the loop).
-#include "conv_common.h"
+#include "../../../bts_amd/csrc/conv_common.h"
 
 namespace bts_conv {
 namespace {
