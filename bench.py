@@ -634,13 +634,15 @@ def main():
         roof["library_md5"] = library_md5()
         if args.dump_launches:
             agg = {}
-            for family, tag, us, work in prof.launches():
-                a = agg.setdefault((family, tag or ""), [0, 0.0, 0.0])
+            for family, tag, us, work, nb in prof.launches():
+                a = agg.setdefault((family, tag or ""), [0, 0.0, 0.0, 0.0])
                 a[0] += 1
                 a[1] += us
                 a[2] += work
+                a[3] += nb
             rows = [{"family": k[0], "tag": k[1], "launches_per_step": round(v[0] / args.steps, 2), "us_per_launch": round(v[1] / v[0], 2),
-                     "us_per_step": round(v[1] / args.steps, 2), "work_per_launch": v[2] / v[0]} for k, v in agg.items()]
+                     "us_per_step": round(v[1] / args.steps, 2), "work_per_launch": v[2] / v[0], "alg_bytes_per_launch": v[3] / v[0]}
+                    for k, v in agg.items()]
             rows.sort(key=lambda r: -r["us_per_step"])
             with open(args.dump_launches, "w") as f:
                 json.dump({"library_md5": roof["library_md5"], "steps": args.steps, "rows": rows}, f, indent=0)
@@ -671,6 +673,10 @@ def main():
         if args.lpg_op and world == 1:
             try:
                 out["roofline_lpg_op"] = lpg_op_roofline(args.batch, args.height, args.width)
+                if (args.batch, args.height, args.width) == (8, 352, 1216):
+                    # the same operator at BASELINE.json configs[4]'s shape (inference, 32 x 704 x 1216): 8x the bytes per launch, so
+                    # the ~2 us a dependent launch costs under graph replay no longer dominates a 14-27 MB kernel
+                    out["roofline_lpg_op_c5"] = lpg_op_roofline(32, 704, 1216, replays=3)
             except Exception as e:   # noqa: BLE001
                 out["roofline_lpg_op"] = {"error": str(e)[:160]}
         if world == 1 and not args.no_cpu_baseline:

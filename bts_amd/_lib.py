@@ -152,12 +152,12 @@ def call(name, *args):
     """Invoke an entry point and raise on a non-zero status."""
     from . import profiler
     if profiler.ACTIVE is not None and name not in _NO_CHECK:
-        note = profiler.take() or (name[4:], "hbm", 0.0, None)      # undescribed launches are still timed (zero work)
+        note = profiler.take() or (name[4:], "hbm", 0.0, None, 0.0)      # undescribed launches are still timed (zero work)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         rc = getattr(load(), name)(*args)
         e.record()
-        profiler.ACTIVE.add(note[0], note[1], note[2], s, e, note[3])
+        profiler.ACTIVE.add(note[0], note[1], note[2], s, e, note[3], note[4])
         if rc != 0:
             raise BtsAmdError("%s failed: %s (%d)" % (name, ERRORS.get(rc, "?"), rc))
         return rc

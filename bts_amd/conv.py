@@ -233,8 +233,10 @@ class ConvLayer:
         if profiler.ACTIVE is not None:
             M = N * Hx * Wx
             kv = sum(pad_to(c, vec_of(dtype)) for c in self.seg_channels) // vec_of(dtype)
+            nb = (sum(t.shape[3] for t in segs) * M * segs[0].element_size() + out.numel() * out.element_size()
+                  + wp.numel() * wp.element_size())            # inputs once + output once + packed weights
             profiler.note(_fwd_kernel(dtype, self.cout, self.kk == 9 and self.dil == 1, (N, Hx, Wx), kv, self.up), "mfma",
-                          2.0 * M * self.nphase * self.T * self.cin * self.cout, self.name + ".fwd")
+                          2.0 * M * self.nphase * self.T * self.cin * self.cout, self.name + ".fwd", nb)
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return out
 
@@ -279,7 +281,9 @@ class ConvLayer:
             cseg = self.seg_channels[seg_index]
             profiler.note(_fwd_kernel(dtype, gx.shape[3], self.kk == 9 and self.dil == 1 and not self.up, (N, Hg, Wg),
                                       pad_to(self.cout, vec_of(dtype)) // vec_of(dtype)), "mfma",
-                          2.0 * N * Hg * Wg * len(self.taps) * cseg * self.cout, "%s.dgrad%d" % (self.name, seg_index))
+                          2.0 * N * Hg * Wg * len(self.taps) * cseg * self.cout, "%s.dgrad%d" % (self.name, seg_index),
+                          dz.numel() * dz.element_size() + wd.numel() * wd.element_size()
+                          + gx.numel() * gx.element_size() * (1 + int(bool(accumulate)) + int(fold_elu_y is not None)))
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return gx
 
@@ -318,7 +322,9 @@ class ConvLayer:
         if profiler.ACTIVE is not None:
             profiler.note("conv_halo<%s>" % _dn(dtype), "mfma",
                           2.0 * N * Hg * Wg * len(self.taps) * (self.seg_channels[i] + self.seg_channels[j]) * self.cout,
-                          "%s.dgrad%d+%d" % (self.name, i, j))
+                          "%s.dgrad%d+%d" % (self.name, i, j),
+                          dz.numel() * dz.element_size() + gx_i.numel() * gx_i.element_size() * (1 + int(bool(acc_i)) + int(fold_i is not None))
+                          + gx_j.numel() * gx_j.element_size() * (1 + int(bool(acc_j))))
         call("bts_conv_fwd", C.byref(d), stream_ptr())
 
     def wgrad_packed(self, segs, dz, dwp):
@@ -336,7 +342,8 @@ class ConvLayer:
         if profiler.ACTIVE is not None:
             cols = self.T * sum(pad_to(c, vec_of(dtype)) for c in self.seg_channels)
             profiler.note(_wgrad_kernel(dtype, self.cout, self.kk == 9 and self.dil == 1, self.up, N, Hx, Wx, cols), "mfma",
-                          2.0 * N * Hx * Wx * self.nphase * self.T * self.cin * self.cout, self.name + ".wgrad")
+                          2.0 * N * Hx * Wx * self.nphase * self.T * self.cin * self.cout, self.name + ".wgrad",
+                          sum(t.numel() for t in segs) * segs[0].element_size() + dz.numel() * dz.element_size() + dwp.numel() * 4 * 2)
         call("bts_conv_wgrad", C.byref(d), C.c_void_p(dz.data_ptr()), pix_stride(dz), C.c_void_p(dwp.data_ptr()), stream_ptr())
         return dwp
 

@@ -364,21 +364,8 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
     //       sources in tools/probes/legacy/.
     //   64 co x 128 px and 32 co x 256 px, 4 waves, for the narrow layers outside conv_halo's domain (1x1 chains, dilated).
     const int epi = epilogue_form(k, BF, true);
-    // EXPERIMENT (r4): short-K launches on 128 co x 64 px tiles (48 KiB: three workgroups per CU, twice the tiles)
-    static const int exp_chunks = [] { const char* e = getenv("BTS_EXP_SHORTK"); return e ? atoi(e) : 0; }();
-    const int nchunks = k.kmajor ? (k.KV >> 3) * k.T : (k.T * k.KV + 7) >> 3;
-    if (BF && k.Cout > 64 && exp_chunks > 0 && nchunks <= exp_chunks) {
-        if constexpr (BF) {
-            if (epi == 1) go(conv_igemm_dma<T, 2, 2, 2, 1, 2, 1, 1>, 128, 64, 256);
-            else if (epi == 2) go(conv_igemm_dma<T, 2, 2, 2, 1, 2, 1, 2>, 128, 64, 256);
-            else if (epi == 3) go(conv_igemm_dma<T, 2, 2, 2, 1, 2, 1, 3>, 128, 64, 256);
-            else if (epi == 4) go(conv_igemm_dma<T, 2, 2, 2, 1, 2, 1, 4>, 128, 64, 256);
-            else if (epi == 5) go(conv_igemm_dma<T, 2, 2, 2, 1, 2, 1, 5>, 128, 64, 256);
-            else go(conv_igemm_dma<T, 2, 2, 2, 1, 2, 1, 0>, 128, 64, 256);
-        }
-        BTS_LAUNCH_CHECK();
-        return BTS_OK;
-    }
+    // (r4, gpurun r04f: the short-K launches -- dense-ASPP 1x1 / dilated 3x3, upconv3 / 4 -- on 128 co x 64 px tiles, 48 KiB = three
+    // workgroups per CU and twice the tiles, are 5-50 % SLOWER than on 128 x 128: not taken)
     if (k.Cout > 64) {
         if constexpr (BF) {
             if (epi == 1) go(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 1>, 128, 128, 256);

@@ -13,15 +13,15 @@ _pending = None
 
 class Profiler:
     def __init__(self):
-        self.records = []   # (family, kind, work, start_evt, end_evt, tag)
+        self.records = []   # (family, kind, work, start_evt, end_evt, tag, algorithmic bytes)
 
-    def add(self, family, kind, work, s, e, tag=None):
-        self.records.append((family, kind, work, s, e, tag))
+    def add(self, family, kind, work, s, e, tag=None, nbytes=0.0):
+        self.records.append((family, kind, work, s, e, tag, nbytes))
 
     def table(self):
         torch.cuda.synchronize()
         fam = {}
-        for family, kind, work, s, e, _tag in self.records:
+        for family, kind, work, s, e, _tag, _nb in self.records:
             f = fam.setdefault(family, {"kind": kind, "ms": 0.0, "work": 0.0, "launches": 0})
             f["ms"] += s.elapsed_time(e)
             f["work"] += work
@@ -29,9 +29,9 @@ class Profiler:
         return fam
 
     def launches(self):
-        """Per-launch list (family, tag, microseconds, work) in issue order."""
+        """Per-launch list (family, tag, microseconds, work, algorithmic bytes) in issue order."""
         torch.cuda.synchronize()
-        return [(family, tag, s.elapsed_time(e) * 1e3, work) for family, kind, work, s, e, tag in self.records]
+        return [(family, tag, s.elapsed_time(e) * 1e3, work, nb) for family, kind, work, s, e, tag, nb in self.records]
 
     def summary(self, mfma_peak_tflops, hbm_peak_gbs, steps):
         fam = self.table()
@@ -92,11 +92,13 @@ def disable():
     ACTIVE = None
 
 
-def note(family, kind, work, tag=None):
-    """Describe the next tracked launch (family name, 'mfma'|'hbm', FLOPs or bytes, optional per-launch tag)."""
+def note(family, kind, work, tag=None, nbytes=None):
+    """Describe the next tracked launch: family name, 'mfma'|'hbm', FLOPs or bytes, optional per-launch tag, and the launch's
+    ALGORITHMIC bytes (for 'hbm' launches that is `work` itself; MFMA launches pass it beside their FLOPs so that the counter
+    traffic of profiles/pmc_traffic.json can be read as a ratio)."""
     global _pending
     if ACTIVE is not None:
-        _pending = (family, kind, float(work), tag)
+        _pending = (family, kind, float(work), tag, float(work if (nbytes is None and kind == "hbm") else (nbytes or 0.0)))
 
 
 def take():

@@ -79,9 +79,24 @@ def load(path, counter):
     return per
 
 
+def alg_bytes(path):
+    """family -> launch-weighted mean algorithmic bytes per C-ABI launch, from a `bench.py --dump-launches` table taken in the SAME
+    configuration as the counter passes (BTS_CONV_WIDE=0)."""
+    import json as _json
+    acc = defaultdict(lambda: [0.0, 0.0])
+    with open(path) as f:
+        for r in _json.load(f)["rows"]:
+            nb = r.get("alg_bytes_per_launch") or 0.0
+            if nb > 0:
+                acc[r["family"]][0] += nb * r["launches_per_step"]
+                acc[r["family"]][1] += r["launches_per_step"]
+    return {k: v[0] / v[1] for k, v in acc.items() if v[1] > 0}
+
+
 def main():
     fpath, wpath, out = sys.argv[1:4]
     md5 = sys.argv[4] if len(sys.argv) > 4 else None
+    alg = alg_bytes(sys.argv[5]) if len(sys.argv) > 5 else {}
     fetch, write = load(fpath, "FETCH_SIZE"), load(wpath, "WRITE_SIZE")
     table = {}
     for fam in sorted(set(fetch) & set(write)):
@@ -92,6 +107,9 @@ def main():
                       "launches_fetch_pass": nf, "launches_write_pass": nw,
                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --graph 0; FETCH_SIZE x2 "
                                 "(gfx950 tallies 128-B requests at 64 B), KiB -> bytes; fabric-side, Infinity-Cache hits included"}
+        if fam in alg:      # (bn_bwd / bn_stats: the counter figure is per KERNEL launch, the algorithmic one per C-ABI call -- see _meta)
+            table[fam]["alg_bytes_per_launch"] = round(alg[fam])
+            table[fam]["traffic_over_algorithmic"] = round((rd + wr) / alg[fam], 2)
     table["_meta"] = {"library_md5": md5, "note": "bn_bwd = reduction + final + apply kernels of one call, bn_stats = partial + final: "
                       "per KERNEL launch here, where bench.py's families count C-ABI calls"}
     with open(out, "w") as f:
