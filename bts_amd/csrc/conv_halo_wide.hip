@@ -44,7 +44,7 @@ constexpr int wide_lds_bytes() { return 2 * PBYTES + NWS * ((NCO * 32 + RP - 1) 
 static_assert(wide_lds_bytes<4>() <= 160 * 1024, "conv_halo_wide: patch double buffer + weight ring exceed the 160 KiB of a CU");
 
 // EPI: epilogue mode fixed at compile time (conv_common.h, conv_epilogue): 0 = generic, 1 = ELU + plain stores, 2 / 3 / 4 = read-modify-write
-// (accumulate / ELU fold / both)
+// (accumulate / ELU fold / both), 5 = no activation + plain stores (a data gradient that is the first writer of its buffer)
 template <int NCO, int EPI = 0>
 __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
     using T = BF16;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NTHR) void conv_halo_wide(const ConvK a) {
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = EPI == 1 ? act_elu_bf16(acc[i][r]) : acc[i][r];
-            if constexpr (EPI == 1) store_block32_plain_bf16(a, opix, cb, fk, v);
+            if constexpr (EPI == 1 || EPI == 5) store_block32_plain_bf16(a, opix, cb, fk, v);
             else if constexpr (EPI == 2) store_block32_rmw_bf16<true, false>(a, opix, cb, fk, v);
             else if constexpr (EPI == 3) store_block32_rmw_bf16<false, true>(a, opix, cb, fk, v);
             else store_block32_rmw_bf16<true, true>(a, opix, cb, fk, v);
@@ -327,7 +327,7 @@ static int launch_halo_wide_n(ConvK& k, hipStream_t st, int force) {
     int epi = 0;
     if (k.vec_store && k.wide_store && !k.y_f32 && k.Cout % 32 == 0 && k.out_scale == 1.f && !k.out_scale_n) {
         if (k.act == BTS_ACT_ELU && !k.accumulate && !k.fold_y) epi = 1;
-        else if (k.act == BTS_ACT_NONE && (k.accumulate || k.fold_y)) epi = k.accumulate ? (k.fold_y ? 4 : 2) : 3;
+        else if (k.act == BTS_ACT_NONE) epi = k.accumulate ? (k.fold_y ? 4 : 2) : (k.fold_y ? 3 : 5);
     }
     const dim3 grid((unsigned)(ntiles * k.n_co_tiles));
 #define BTS_WIDE_(E) hipLaunchKernelGGL((conv_halo_wide<NCO, E>), grid, dim3(NTHR), 0, st, k)
@@ -335,6 +335,7 @@ static int launch_halo_wide_n(ConvK& k, hipStream_t st, int force) {
     else if (epi == 2) BTS_WIDE_(2);
     else if (epi == 3) BTS_WIDE_(3);
     else if (epi == 4) BTS_WIDE_(4);
+    else if (epi == 5) BTS_WIDE_(5);
     else BTS_WIDE_(0);
 #undef BTS_WIDE_
     if (hipGetLastError() != hipSuccess) return BTS_ERR_LAUNCH;
