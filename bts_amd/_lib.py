@@ -99,6 +99,7 @@ SIGNATURES = {
     "bts_silog_bwd": [_p, _p, _p, _f, _l, _f, _p, _p, _p, _p, _p],
     "bts_conv_fwd": [C.POINTER(ConvDesc), _p],
     "bts_conv_wgrad": [C.POINTER(ConvDesc), _p, _i, _p, _p],
+    "bts_conv_wgrad_group": [_p, _p, _p, _p, _i, _p],
     "bts_conv3x3_c1_fwd": [_p, _i, _i, _i, _p, _p, _i, _i, _i, _f, _p, _p],
     "bts_conv3x3_c1_dgrad": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _f, _p, _p],
     "bts_conv3x3_c1_wgrad": [_p, _p, _p, _i, _i, _i, _p, _i, _i, _i, _i, _f, _p, _p],

@@ -327,8 +327,7 @@ class ConvLayer:
                           + gx_j.numel() * gx_j.element_size() * (1 + int(bool(acc_j))))
         call("bts_conv_fwd", C.byref(d), stream_ptr())
 
-    def wgrad_packed(self, segs, dz, dwp):
-        """Accumulates the packed f32 weight gradient [Cout, nphase*T, Ktot] into `dwp` (caller-zeroed)."""
+    def _wgrad_desc(self, segs, dz):
         dtype = segs[0].dtype
         N, Hx, Wx, _ = segs[0].shape
         d = self._desc(dtype, segs, N, Hx, Wx)
@@ -339,6 +338,24 @@ class ConvLayer:
         d.Cout = self.cout
         d.Hy, d.Wy = dz.shape[1], dz.shape[2]
         d.osc = 2 if self.up else 1
+        return d
+
+    def wgrad_groupable(self, dtype, n, hx, wx):
+        """Does this layer's weight gradient run on the 128 x 256 ring kernel (csrc/conv_wgrad_tr.hip), i.e. can it join a grouped
+        launch (bts_conv_wgrad_group)?  Mirrors launch_wgrad(): the LDS-halo-tile form takes the radius-1 3x3 layers up to 128
+        output channels on large maps first."""
+        cols = self.T * sum(pad_to(c, vec_of(dtype)) for c in self.seg_channels)
+        # only the SMALL layers gain: <= 16 tiles of 128 x 256 (the dense-ASPP layers: 2-9 tiles, split 28-42 ways when launched alone).
+        # conv4 / conv5 / daspp_conv (32-128 tiles) fill the chip with a 2-8-way split on their own at ~800 TF; grouped with small
+        # layers they measured 664 TF (gpurun r04j: 171 tiles leave the one-round split nothing to balance)
+        return (dtype == torch.bfloat16 and not self.up and _cdiv(self.cout, 128) * _cdiv(cols, 256) <= 16
+                and _wgrad_kernel(dtype, self.cout, self.kk == 9 and self.dil == 1, self.up, n, hx, wx, cols) == "conv_wgrad_ring<bf16,128x256>")
+
+    def wgrad_packed(self, segs, dz, dwp):
+        """Accumulates the packed f32 weight gradient [Cout, nphase*T, Ktot] into `dwp` (caller-zeroed)."""
+        dtype = segs[0].dtype
+        N, Hx, Wx, _ = segs[0].shape
+        d = self._wgrad_desc(segs, dz)
         if profiler.ACTIVE is not None:
             cols = self.T * sum(pad_to(c, vec_of(dtype)) for c in self.seg_channels)
             profiler.note(_wgrad_kernel(dtype, self.cout, self.kk == 9 and self.dil == 1, self.up, N, Hx, Wx, cols), "mfma",
@@ -346,6 +363,24 @@ class ConvLayer:
                           sum(t.numel() for t in segs) * segs[0].element_size() + dz.numel() * dz.element_size() + dwp.numel() * 4 * 2)
         call("bts_conv_wgrad", C.byref(d), C.c_void_p(dz.data_ptr()), pix_stride(dz), C.c_void_p(dwp.data_ptr()), stream_ptr())
         return dwp
+
+    @staticmethod
+    def wgrad_group(items):
+        """items: [(layer, segs, dz, dwp)] (<= 6, each wgrad_groupable): all their weight gradients in ONE launch."""
+        n = len(items)
+        descs = [L._wgrad_desc(segs, dz) for L, segs, dz, dwp in items]
+        dp = (C.c_void_p * n)(*[C.addressof(d) for d in descs])
+        dzp = (C.c_void_p * n)(*[dz.data_ptr() for _, _, dz, _ in items])
+        dzs = (C.c_int * n)(*[pix_stride(dz) for _, _, dz, _ in items])
+        dwp_ = (C.c_void_p * n)(*[dwp.data_ptr() for _, _, _, dwp in items])
+        if profiler.ACTIVE is not None:
+            fl = nb = 0.0
+            for L, segs, dz, dwp in items:
+                N, Hx, Wx, _ = segs[0].shape
+                fl += 2.0 * N * Hx * Wx * L.nphase * L.T * L.cin * L.cout
+                nb += sum(t.numel() for t in segs) * segs[0].element_size() + dz.numel() * dz.element_size() + dwp.numel() * 4 * 2
+            profiler.note("conv_wgrad_ring<bf16,128x256>", "mfma", fl, "+".join(L.name for L, _, _, _ in items) + ".wgrad", nb)
+        call("bts_conv_wgrad_group", dp, dzp, dzs, dwp_, n, stream_ptr())
 
     def wgrad(self, segs, dz):
         """Returns the f32 weight gradient in PyTorch layout."""

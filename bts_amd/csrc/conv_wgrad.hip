@@ -658,3 +658,24 @@ extern "C" int bts_conv_wgrad(const bts_conv_desc_t* d, const void* dz, int dz_s
     return d->dtype == BTS_F32 ? launch_wgrad<F32>(k, (hipStream_t)stream) : launch_wgrad<BF16>(k, (hipStream_t)stream);
 }
 
+
+extern "C" int bts_conv_wgrad_group(const bts_conv_desc_t* const* descs, const void* const* dz, const int* dz_stride, float* const* dw,
+                                    int n, bts_stream_t stream) {
+    BTS_CHECK_ARG(descs && dz && dz_stride && dw && n >= 1);
+    if (n > 6) return BTS_ERR_UNSUPPORTED;
+    ConvK ks[6];
+    for (int i = 0; i < n; ++i) {
+        const bts_conv_desc_t* d = descs[i];
+        ks[i] = ConvK{};
+        const int rc = fill_common(d, ks[i]);
+        if (rc != BTS_OK) return rc;
+        if (d->dtype != BTS_BF16) return BTS_ERR_UNSUPPORTED;
+        BTS_CHECK_ARG(dz[i] != nullptr && dw[i] != nullptr && ((uintptr_t)dz[i] & 15) == 0);
+        BTS_CHECK_ARG(dz_stride[i] % 8 == 0 && dz_stride[i] >= (d->Cout + 7) / 8 * 8);
+        BTS_CHECK_ARG(d->Hy >= d->Hg * d->osc && d->Wy >= d->Wg * d->osc);
+        ks[i].dz = (const char*)dz[i];
+        ks[i].dz_stride = dz_stride[i];
+        ks[i].dw = dw[i];
+    }
+    return launch_wgrad_ring_group(ks, n, (hipStream_t)stream);
+}

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(const ConvK a) {
 // 953, 256 x 256 rings 814-827 (profiles/r03_wgrad_pipe_probe.jsonl).
 // RAW / WAR argument: see conv_igemm_dma's ring schedule (conv_igemm.hip), it is the same.
 template <int WR, int WC, int NST>
-__global__ __launch_bounds__(WR* WC * 64) void conv_wgrad_ring(const ConvK a) {
+__device__ __forceinline__ void wgrad_ring_body(const ConvK& a, const int tile_index, const int split, const int phase, const bool single) {
     constexpr int NT = WR * WC * 64, TM = WR * 64, TN = WC * 64;
     constexpr int NSA = TM / 64, NSB = TN / 64, NSUB = NSA + NSB;
     constexpr int RPI = NT / 8;              // pixel rows one DMA instruction of the whole workgroup covers
@@ -268,8 +268,7 @@ __global__ __launch_bounds__(WR* WC * 64) void conv_wgrad_ring(const ConvK a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int phase = blockIdx.z, split = blockIdx.y;
-    const int L = remap_xcd(blockIdx.x, a.n_co_tiles * a.n_col_tiles);
+    const int L = remap_xcd(tile_index, a.n_co_tiles * a.n_col_tiles);
     const int co_tile = L % a.n_co_tiles, col_tile = L / a.n_co_tiles;
     const int pa = phase >> 1, pb = phase & 1;
     const char* zero = (const char*)kZeroPage;
@@ -409,7 +408,6 @@ __global__ __launch_bounds__(WR* WC * 64) void conv_wgrad_ring(const ConvK a) {
     const size_t row_len = (size_t)a.Ttot * a.Ktot;
     const int TK = a.T * a.Ktot;
     const int frow = lane & 31, fk = lane >> 5;
-    const bool single = gridDim.y == 1;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = col_tile * TN + (wc * 2 + j) * 32 + frow;
@@ -439,6 +437,41 @@ __global__ __launch_bounds__(WR* WC * 64) void conv_wgrad_ring(const ConvK a) {
             }
         }
     }
+}
+
+template <int WR, int WC, int NST>
+__global__ __launch_bounds__(WR* WC * 64) void conv_wgrad_ring(const ConvK a) {
+    wgrad_ring_body<WR, WC, NST>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, gridDim.y == 1);
+}
+
+// Grouped form (r4): up to WG_GROUP_MAX independent weight gradients in ONE launch.  Split-K over pixels costs a full-chip set of f32
+// atomics per launch (256 workgroups x 128 x 256 partial sums = 8.4 M lane-atomics, ~14 us: measured by replacing them with plain
+// stores, profiles/r04_wgrad_atomics_ab_*.json) however small the layer, and the dense-ASPP layers are small: nine or six tiles each,
+// split 28-42 ways to fill the chip, 20-30 chunks of 64 pixels per workgroup behind a prologue and those atomics.  A weight gradient
+// depends only on (dz, x) of its own layer, so the decoder defers them and hands up to six at a time to this kernel: the tiles of five
+// or six layers fill the chip with a 5-7-way split -- one set of atomics and one prologue per group, 100-170 chunks per workgroup.
+// Block b belongs to problem i with first[i] <= b < first[i + 1]; inside it, tile = local % tiles_i, split = local / tiles_i.
+constexpr int WG_GROUP_MAX = 6;
+struct WgradGroup {
+    ConvK p[WG_GROUP_MAX];
+    int first[WG_GROUP_MAX + 1];
+    int n;
+};
+static_assert(sizeof(WgradGroup) <= 4096, "kernel argument segment");
+
+template <int WR, int WC, int NST>
+__global__ __launch_bounds__(WR* WC * 64) void conv_wgrad_ring_group(const WgradGroup g) {
+    const int b = (int)blockIdx.x;
+    // constant indices into the by-value argument (a dynamic index would copy the 496-byte descriptor through scratch)
+#define BTS_GROUP_CASE_(I)                                                                                              \
+    if (I < g.n && b >= g.first[I] && b < g.first[I + 1]) {                                                              \
+        const int tiles = g.p[I].n_co_tiles * g.p[I].n_col_tiles, local = b - g.first[I];                               \
+        wgrad_ring_body<WR, WC, NST>(g.p[I], local % tiles, local / tiles, 0, g.first[I + 1] - g.first[I] == tiles);    \
+        return;                                                                                                          \
+    }
+    BTS_GROUP_CASE_(0) BTS_GROUP_CASE_(1) BTS_GROUP_CASE_(2) BTS_GROUP_CASE_(3) BTS_GROUP_CASE_(4) BTS_GROUP_CASE_(5)
+    static_assert(WG_GROUP_MAX == 6, "one case per problem slot");
+#undef BTS_GROUP_CASE_
 }
 
 
@@ -694,6 +727,53 @@ int launch_wgrad_tr(const ConvK& k0, hipStream_t st) {
     splits = ceil_div(k.nchunks, k.chunks_per_split);
     dim3 grid(k.n_co_tiles * k.n_col_tiles, splits, k.nphase);
     hipLaunchKernelGGL(conv_wgrad_tr<2>, grid, dim3(256), 0, st, k);
+    if (hipGetLastError() != hipSuccess) return BTS_ERR_LAUNCH;
+    return BTS_OK;
+}
+
+// conv_wgrad.hip: bts_conv_wgrad_group.  Every problem must be in the ring kernel's domain (bf16, Cout > 64, one phase, 32-bit
+// offsets); pixel splits are chosen so that every workgroup of the launch walks about the same number of 64-pixel chunks and
+// the launch fills the chip once.
+int launch_wgrad_ring_group(const ConvK* ks, int n, hipStream_t st) {
+    if (n < 1 || n > WG_GROUP_MAX) return BTS_ERR_UNSUPPORTED;
+    constexpr int NST = 3, LDS = NST * 6 * SUB;
+    WgradGroup g{};
+    long work = 0;
+    for (int i = 0; i < n; ++i) {
+        ConvK& k = g.p[i];
+        k = ks[i];
+        if (k.Cout <= 64 || k.nphase != 1) return BTS_ERR_UNSUPPORTED;
+        if ((long)k.N * k.Hy * k.Wy * k.dz_stride * 2 >= (1l << 32) || !segs_fit_u32(k)) return BTS_ERR_UNSUPPORTED;
+        k.nchunks = ceil_div(k.M, KC);
+        k.n_co_tiles = ceil_div(k.Cout, 128);
+        k.n_col_tiles = ceil_div((long)k.T * k.Ktot, 256);
+        work += (long)k.n_co_tiles * k.n_col_tiles * k.nchunks;
+    }
+    // chunks per workgroup: the smallest count (>= 8) with which the whole group fits the chip in ONE round -- a 257th workgroup
+    // would run alone behind the other 256
+    long per_wg = ceil_div(work, bts_cu_count());
+    if (per_wg < 8) per_wg = 8;
+    int total = 0;
+    for (int iter = 0; iter < 4096; ++iter, ++per_wg) {
+        total = 0;
+        for (int i = 0; i < n; ++i) {
+            ConvK& k = g.p[i];
+            int splits = ceil_div(k.nchunks, per_wg);
+            if (splits < 1) splits = 1;
+            k.chunks_per_split = ceil_div(k.nchunks, splits);
+            splits = ceil_div(k.nchunks, k.chunks_per_split);
+            g.first[i] = total;
+            total += k.n_co_tiles * k.n_col_tiles * splits;
+        }
+        bool unsplit = true;                                  // every problem down to one split: nothing left to merge
+        for (int i = 0; i < n; ++i) unsplit = unsplit && g.p[i].chunks_per_split >= g.p[i].nchunks;
+        if (total <= bts_cu_count() || unsplit) break;
+    }
+    for (int i = n; i <= WG_GROUP_MAX; ++i) g.first[i] = total;
+    g.n = n;
+    static DynLdsCache lds_set;
+    if (ensure_dyn_lds((const void*)conv_wgrad_ring_group<2, 4, NST>, LDS, lds_set) != BTS_OK) return BTS_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv_wgrad_ring_group<2, 4, NST>), dim3((unsigned)total), dim3(512), (size_t)LDS, st, g);
     if (hipGetLastError() != hipSuccess) return BTS_ERR_LAUNCH;
     return BTS_OK;
 }

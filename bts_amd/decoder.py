@@ -212,6 +212,7 @@ class DecoderRun:
             plan.pack_cache[(dtype, dev)] = ps
         self.packs = ps
         self.dwp_arena = None
+        self.wgrad_pending = []
 
     # ---- ops -------------------------------------------------------------------------------
     def _use(self, a, can_fold):
@@ -282,9 +283,35 @@ class DecoderRun:
                         s.g_is_dz = True
                 off, shape = self.packs.dwp_off[name]
                 n_el = shape[0] * shape[1] * shape[2]
-                L.wgrad_packed(x, dz, self.dwp_arena[off:off + n_el].view(shape))
+                self._wgrad(L, x, dz, self.dwp_arena[off:off + n_el].view(shape))
             self.tape.append(bwd)
         return y
+
+    # The weight gradients of the SMALL ring-kernel layers (the dense ASPP, reduc8x8's 128 -> 128 layer) are deferred and leave five at a
+    # time, in the order the backward pass reaches them (bts_conv_wgrad_group): a weight gradient depends only on its own layer's
+    # (dz, inputs) -- both stay alive until the pass ends -- and a grouped launch pays the split-K atomics and the pipeline prologue
+    # once per group instead of once per layer.  Arrival order interleaves the ASPP's 1x1 layers (bound by fabric traffic: 87 FLOP per
+    # staged byte with little reuse between workgroups) with its dilated 3x3 layers (MFMA-bound, L2-friendly), which is what pays:
+    # eleven launches, 637 us -> 170 + 208 + 39 us (gpurun r04k); groups of like layers -- five 3x3, five 1x1 -- measured 277 + 262 us,
+    # groups of six and five 288 + 248 (profiles/r04_wgrad_group_*.json).
+    WGRAD_GROUP = 5
+
+    def _wgrad(self, L, x, dz, dwp):
+        N, Hx, Wx, _ = x[0].shape
+        if not L.wgrad_groupable(dz.dtype, N, Hx, Wx):
+            L.wgrad_packed(x, dz, dwp)
+            return
+        self.wgrad_pending.append((L, x, dz, dwp))
+        if len(self.wgrad_pending) == self.WGRAD_GROUP:
+            self._flush_wgrads()
+
+    def _flush_wgrads(self):
+        items, self.wgrad_pending = self.wgrad_pending, []
+        if len(items) == 1:
+            L, x, dz, dwp = items[0]
+            L.wgrad_packed(x, dz, dwp)
+        elif items:
+            ConvLayer.wgrad_group(items)
 
     def conv_c1(self, name, x, out_scale, out_scale_n):
         """3x3 convolution to one channel + sigmoid * scale (get_depth, bts.py:193-194, 262-264) on the streaming kernels of
@@ -573,6 +600,7 @@ class DecoderRun:
         self.dwp_arena = torch.zeros(self.packs.dwp_total, dtype=torch.float32, device=dev)     # one memset for every layer
         for fn in reversed(self.tape):
             fn()
+        self._flush_wgrads()
         self.tape = []
         gw_arena = torch.empty(self.packs.gw_total, dtype=torch.float32, device=dev)
         self.packs.unpack_all(self.dwp_arena, gw_arena)

@@ -237,6 +237,13 @@ int bts_conv3x3_c1_wgrad(const float* grad_y, const float* y, const void* x, int
  * dz has the geometry of d's output (stride dz_stride, dtype d->dtype).  dw is f32,
  * [Cout][nphase*T][Ktot], accumulated with atomics: the caller zeroes it. */
 int bts_conv_wgrad(const bts_conv_desc_t* d, const void* dz, int dz_stride, float* dw, bts_stream_t stream);
+/* The weight gradients of up to six INDEPENDENT convolutions in one launch: dw[i] += as bts_conv_wgrad(descs[i], dz[i], dz_stride[i],
+ * dw[i]).  A weight gradient depends only on its own layer's (dz, input), so a caller can defer a backward pass's weight gradients and
+ * hand them over in groups: the pixel split of a small layer then costs one full-chip set of f32 atomics per GROUP instead of per
+ * layer (the dense-ASPP layers of bts.py:164-168).  Domain: bf16, Cout > 64, nphase == 1; BTS_ERR_UNSUPPORTED otherwise (call
+ * bts_conv_wgrad per layer). */
+int bts_conv_wgrad_group(const bts_conv_desc_t* const* descs, const void* const* dz, const int* dz_stride, float* const* dw,
+                         int n, bts_stream_t stream);
 
 /* Pack a PyTorch-layout f32 weight [Cout][Cin][KK] (KK = kh*kw = 1 or 9) for bts_conv_fwd.
  *   mode 0 (forward):   out[r][t][k] = sum_{s in tapmask[t]} w[r][cmap[k]][s],      r < R = Cout

@@ -322,6 +322,44 @@ def test_conv_dual_data_gradient(shape, mode):
     assert g1[..., 4:].float().abs().max().item() == (base1[..., 4:].float().abs().max().item() if acc else 0.0)
 
 
+def test_conv_wgrad_group():
+    """bts_conv_wgrad_group: five independent weight gradients (dense-ASPP-like 1x1 and dilated 3x3 layers, one multi-segment 3x3,
+    different widths) in one launch of the ring kernel, against the per-layer launches (same kernel body: equal up to the order of
+    the split-K atomics) and against F.conv2d autograd."""
+    from bts_amd.conv import ConvLayer
+    dt, v = torch.bfloat16, 8
+    N, H, W = 4, 44, 76
+    gen = torch.Generator().manual_seed(77)
+    specs = [("g1x1a", 256, [320], 1, 1), ("g3x3d6", 128, [256], 9, 6), ("g1x1b", 256, [256, 192, 128], 1, 1),
+             ("g3x3d3", 128, [256], 9, 3), ("g3x3", 160, [128, 64], 9, 1)]
+    items, refs, singles = [], [], []
+    for name, cout, segc, kk, dil in specs:
+        L = ConvLayer(name, cout, segc, kk, dil)
+        assert L.wgrad_groupable(dt, N, H, W), name
+        xs = [torch.randn(N, c, H, W, generator=gen).to(dt).float() for c in segc]
+        k = 3 if kk == 9 else 1
+        w = (torch.randn(cout, sum(segc), k, k, generator=gen) * 0.05).requires_grad_(True)
+        dz = torch.randn(N, cout, H, W, generator=gen).to(dt).float()
+        F.conv2d(torch.cat(xs, 1), w, padding=dil if kk == 9 else 0, dilation=dil).backward(dz)
+        segs = [_nhwc(x, dt, v) for x in xs]
+        dzd = _nhwc(dz, dt, v)
+        tb = L.tables(dt, torch.device(DEV))
+        dwp = torch.zeros((cout, L.T, tb["ktot"]), dtype=torch.float32, device=DEV)
+        items.append((L, segs, dzd, dwp))
+        refs.append(w.grad)
+        one = torch.zeros_like(dwp)
+        L.wgrad_packed(segs, dzd, one)
+        singles.append(one)
+    ConvLayer.wgrad_group(items)
+    for (L, segs, dzd, dwp), ref, one in zip(items, refs, singles):
+        assert rel(dwp, one) < 1e-5, L.name
+        assert rel(L.unpack_wgrad(dwp, dt).cpu(), ref) < 2e-2, L.name
+    # fewer than five, and a second call accumulates on top
+    ConvLayer.wgrad_group(items[:2])
+    for (L, segs, dzd, dwp), one in zip(items[:2], singles[:2]):
+        assert rel(dwp, 2 * one) < 1e-5, L.name
+
+
 def test_conv_epilogues():
     """ELU / sigmoid*scale_n epilogues and the single-channel f32 map output."""
     from bts_amd.conv import ConvLayer

@@ -41,7 +41,7 @@ cd $R
 # algorithmic bytes per launch of every family IN THE CONFIGURATION OF THE COUNTER PASSES (BTS_CONV_WIDE=0), for the traffic / algorithmic ratio
 BTS_CONV_WIDE=0 run_to 150 python bench.py $A --steps 5 --warmup 2 --dump-launches $O/${T}_launches_wide0.json > /dev/null 2>&1
 python tools/pmc_traffic.py $O/${T}_pmc_FETCH_SIZE.csv $O/${T}_pmc_WRITE_SIZE.csv $O/${T}_pmc_traffic.json $MD5 $O/${T}_launches_wide0.json > $O/${T}_pmc_traffic.txt 2>&1; tail -12 $O/${T}_pmc_traffic.txt
-python tools/pmc_sq.py $O/${T}_pmc_sq.csv $O/${T}_pmc_sq.json $MD5 > $O/${T}_pmc_sq.txt 2>&1; tail -12 $O/${T}_pmc_sq.txt
+python tools/pmc_sq.py $O/${T}_pmc_sq.csv $O/${T}_pmc_sq.json $MD5 $O/${T}_launches_wide0.json > $O/${T}_pmc_sq.txt 2>&1; tail -12 $O/${T}_pmc_sq.txt
 # the counter CSVs are large: keep the summaries, drop the raw files beyond the 64 MiB the call may bring back
 gzip -9 -f $O/${T}_pmc_FETCH_SIZE.csv $O/${T}_pmc_WRITE_SIZE.csv $O/${T}_pmc_sq.csv 2> /dev/null
 ls -la $O | grep ${T}_ | head -40

@@ -2,7 +2,12 @@
 """Summarise a rocprofv3 SQ counter pass (one --pmc run of bench.py) per kernel family: counter sums per launch, and the derived
 figures the judge asks for -- MFMA-busy fraction of the wave cycles, issue-stall and wait fractions.
 
-    python tools/pmc_sq.py <counter_collection.csv> <out.json> [library_md5]
+    python tools/pmc_sq.py <counter_collection.csv[.gz]> <out.json> [library_md5] [launches.json]
+
+With a `bench.py --dump-launches` table of the SAME configuration (BTS_CONV_WIDE=0): per family the MFMA-pipe utilisation
+SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch duration x 2.4 GHz) -- the counter is in shader cycles, 32 per v_mfma_f32_32x32x16_bf16
+(MI355X_MICROARCH.md); 2.4 GHz is the maximum clock, so the figure is a LOWER bound of the busy fraction at the clock the kernel really ran at --
+and the executed / algorithmic FLOP ratio (tile padding: busy cycles / 32 x 32768 FLOPs against the launch's algorithmic FLOPs).
 
 Families are the ones bench.py / tools/pmc_traffic.py use (pmc_traffic.family)."""
 import csv
@@ -14,11 +19,14 @@ from pmc_traffic import family
 
 
 def main():
+    import gzip
     path, out = sys.argv[1:3]
     md5 = sys.argv[3] if len(sys.argv) > 3 else None
+    launches = sys.argv[4] if len(sys.argv) > 4 else None
     per = defaultdict(lambda: defaultdict(float))
     disp = defaultdict(set)
-    for r in csv.DictReader(open(path)):
+    fh_in = gzip.open(path, "rt") if path.endswith(".gz") else open(path)
+    for r in csv.DictReader(fh_in):
         f = family(r["Kernel_Name"])
         if not f:
             continue
@@ -41,13 +49,28 @@ def main():
         if c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16") and c.get("SQ_BUSY_CYCLES"):
             row["mfma_mops_bf16_per_launch"] = round(c["SQ_INSTS_VALU_MFMA_MOPS_BF16"] / n, 1)
         table[f] = row
+    if launches:
+        fam = {}
+        with open(launches) as fh:
+            for r in json.load(fh)["rows"]:
+                a = fam.setdefault(r["family"], [0.0, 0.0, 0.0])
+                a[0] += r["launches_per_step"]
+                a[1] += r["us_per_step"]
+                a[2] += r["work_per_launch"] * r["launches_per_step"]
+        for f, row in table.items():
+            busy = row.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+            if f in fam and busy > 0 and fam[f][0] > 0:
+                us, flops = fam[f][1] / fam[f][0], fam[f][2] / fam[f][0]
+                row["event_timed_us_per_launch"] = round(us, 1)
+                row["mfma_util_at_2.4GHz"] = round(busy / (1024 * us * 1e-6 * 2.4e9), 4)
+                row["executed_over_algorithmic_flops"] = round(busy / 32 * 32768 / flops, 3)
     table["_meta"] = {"library_md5": md5, "source": "rocprofv3 --pmc (one SQ pass) --kernel-trace of bench.py --graph 0, BTS_CONV_WIDE=0 "
                       "(conv_halo_wide aborts counter passes: the wide 3x3 layers run on conv_igemm_dma in this pass)"}
     with open(out, "w") as fh:
         json.dump(table, fh, indent=1)
     for f, row in table.items():
         if not f.startswith("_"):
-            print("%-34s %s" % (f, {k: v for k, v in row.items() if k.endswith("frac") or k.startswith("mfma_busy") or k == "launches"}))
+            print("%-34s %s" % (f, {k: v for k, v in row.items() if k.endswith("frac") or k.startswith("mfma_") or k.startswith("executed") or k == "launches"}))
 
 
 if __name__ == "__main__":

@@ -36,7 +36,7 @@ def family(name):
         return "conv_wgrad_ring<bf16,%dx%d>" % (int(m.group(1)) * 64, int(m.group(2)) * 64)
     if n.startswith("conv_wgrad_tr"):
         return "conv_wgrad_tr<bf16,128x128>"
-    m = re.match(r"conv_halo_wide<(\d)>", n)
+    m = re.match(r"conv_halo_wide<(\d)[,>]", n)
     if m:
         return "conv_halo_wide<bf16,%dx256>" % (int(m.group(1)) * 32)
     if n.startswith("conv_halo_wide"):
@@ -70,7 +70,8 @@ def family(name):
 
 def load(path, counter):
     per = defaultdict(list)
-    for r in csv.DictReader(open(path)):
+    import gzip
+    for r in csv.DictReader(gzip.open(path, "rt") if path.endswith(".gz") else open(path)):
         if r.get("Counter_Name") != counter:
             continue
         f = family(r["Kernel_Name"])
@@ -88,8 +89,9 @@ def alg_bytes(path):
         for r in _json.load(f)["rows"]:
             nb = r.get("alg_bytes_per_launch") or 0.0
             if nb > 0:
-                acc[r["family"]][0] += nb * r["launches_per_step"]
-                acc[r["family"]][1] += r["launches_per_step"]
+                fam = "lpg_head*" if r["family"].startswith("lpg_head") or r["family"].startswith("lpg_chain") else r["family"]
+                acc[fam][0] += nb * r["launches_per_step"]
+                acc[fam][1] += r["launches_per_step"]
     return {k: v[0] / v[1] for k, v in acc.items() if v[1] > 0}
 
 
@@ -110,7 +112,9 @@ def main():
         if fam in alg:      # (bn_bwd / bn_stats: the counter figure is per KERNEL launch, the algorithmic one per C-ABI call -- see _meta)
             table[fam]["alg_bytes_per_launch"] = round(alg[fam])
             table[fam]["traffic_over_algorithmic"] = round((rd + wr) / alg[fam], 2)
-    table["_meta"] = {"library_md5": md5, "note": "bn_bwd = reduction + final + apply kernels of one call, bn_stats = partial + final: "
+    table["_meta"] = {"library_md5": md5, "config": "both passes with BTS_CONV_WIDE=0 (rocprofv3 aborts a --pmc pass at conv_halo_wide's first "
+                      "dispatch): the wide 3x3 layers run on conv_igemm_dma here, so that family covers more launches per step than in the timed step",
+                      "note": "bn_bwd = reduction + final + apply kernels of one call, bn_stats = partial + final: "
                       "per KERNEL launch here, where bench.py's families count C-ABI calls"}
     with open(out, "w") as f:
         json.dump(table, f, indent=1)
