@@ -366,7 +366,7 @@ class ConvLayer:
 
     @staticmethod
     def wgrad_group(items):
-        """items: [(layer, segs, dz, dwp)] (<= 6, each wgrad_groupable): all their weight gradients in ONE launch."""
+        """items: [(layer, segs, dz, dwp)] (<= 5, each wgrad_groupable): all their weight gradients in ONE launch."""
         n = len(items)
         descs = [L._wgrad_desc(segs, dz) for L, segs, dz, dwp in items]
         dp = (C.c_void_p * n)(*[C.addressof(d) for d in descs])

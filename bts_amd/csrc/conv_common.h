@@ -440,7 +440,7 @@ int launch_wgrad_ring64(const ConvK& k, hipStream_t st);
 // when the shape is outside its domain (the caller then falls back to conv_wgrad).
 int launch_wgrad_tr(const ConvK& k, hipStream_t st);
 
-// conv_wgrad_tr.hip: up to six independent bf16 weight gradients with > 64 output channels in ONE launch of the ring kernel
+// conv_wgrad_tr.hip: up to five independent bf16 weight gradients with > 64 output channels in ONE launch of the ring kernel
 // (one set of split-K atomics and one prologue for all of them); BTS_ERR_UNSUPPORTED outside that domain
 int launch_wgrad_ring_group(const ConvK* ks, int n, hipStream_t st);
 

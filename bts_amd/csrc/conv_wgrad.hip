@@ -662,8 +662,8 @@ extern "C" int bts_conv_wgrad(const bts_conv_desc_t* d, const void* dz, int dz_s
 extern "C" int bts_conv_wgrad_group(const bts_conv_desc_t* const* descs, const void* const* dz, const int* dz_stride, float* const* dw,
                                     int n, bts_stream_t stream) {
     BTS_CHECK_ARG(descs && dz && dz_stride && dw && n >= 1);
-    if (n > 6) return BTS_ERR_UNSUPPORTED;
-    ConvK ks[6];
+    if (n > 5) return BTS_ERR_UNSUPPORTED;
+    ConvK ks[5];
     for (int i = 0; i < n; ++i) {
         const bts_conv_desc_t* d = descs[i];
         ks[i] = ConvK{};

@@ -448,10 +448,10 @@ __global__ __launch_bounds__(WR* WC * 64) void conv_wgrad_ring(const ConvK a) {
 // atomics per launch (256 workgroups x 128 x 256 partial sums = 8.4 M lane-atomics, ~14 us: measured by replacing them with plain
 // stores, profiles/r04_wgrad_atomics_ab_*.json) however small the layer, and the dense-ASPP layers are small: nine or six tiles each,
 // split 28-42 ways to fill the chip, 20-30 chunks of 64 pixels per workgroup behind a prologue and those atomics.  A weight gradient
-// depends only on (dz, x) of its own layer, so the decoder defers them and hands up to six at a time to this kernel: the tiles of five
-// or six layers fill the chip with a 5-7-way split -- one set of atomics and one prologue per group, 100-170 chunks per workgroup.
+// depends only on (dz, x) of its own layer, so the decoder defers them and hands five at a time to this kernel: the tiles of five
+// layers fill the chip with a 5-7-way split -- one set of atomics and one prologue per group, 100-170 chunks per workgroup.
 // Block b belongs to problem i with first[i] <= b < first[i + 1]; inside it, tile = local % tiles_i, split = local / tiles_i.
-constexpr int WG_GROUP_MAX = 6;
+constexpr int WG_GROUP_MAX = 5;
 struct WgradGroup {
     ConvK p[WG_GROUP_MAX];
     int first[WG_GROUP_MAX + 1];
@@ -469,8 +469,11 @@ __global__ __launch_bounds__(WR* WC * 64) void conv_wgrad_ring_group(const Wgrad
         wgrad_ring_body<WR, WC, NST>(g.p[I], local % tiles, local / tiles, 0, g.first[I + 1] - g.first[I] == tiles);    \
         return;                                                                                                          \
     }
-    BTS_GROUP_CASE_(0) BTS_GROUP_CASE_(1) BTS_GROUP_CASE_(2) BTS_GROUP_CASE_(3) BTS_GROUP_CASE_(4) BTS_GROUP_CASE_(5)
-    static_assert(WG_GROUP_MAX == 6, "one case per problem slot");
+    // FIVE slots, not more: every slot is one inlined copy of the loop body, and with six the same two groups of the bench step ran
+    // 1.3-1.45x slower (272 / 248 us against 208 / 170 with five: gpurun r04k vs r04final2, same layers, same splits) -- the copies a
+    // CU's neighbours execute compete for the shared instruction cache
+    BTS_GROUP_CASE_(0) BTS_GROUP_CASE_(1) BTS_GROUP_CASE_(2) BTS_GROUP_CASE_(3) BTS_GROUP_CASE_(4)
+    static_assert(WG_GROUP_MAX == 5, "one case per problem slot");
 #undef BTS_GROUP_CASE_
 }
 

@@ -237,7 +237,7 @@ int bts_conv3x3_c1_wgrad(const float* grad_y, const float* y, const void* x, int
  * dz has the geometry of d's output (stride dz_stride, dtype d->dtype).  dw is f32,
  * [Cout][nphase*T][Ktot], accumulated with atomics: the caller zeroes it. */
 int bts_conv_wgrad(const bts_conv_desc_t* d, const void* dz, int dz_stride, float* dw, bts_stream_t stream);
-/* The weight gradients of up to six INDEPENDENT convolutions in one launch: dw[i] += as bts_conv_wgrad(descs[i], dz[i], dz_stride[i],
+/* The weight gradients of up to five INDEPENDENT convolutions in one launch: dw[i] += as bts_conv_wgrad(descs[i], dz[i], dz_stride[i],
  * dw[i]).  A weight gradient depends only on its own layer's (dz, input), so a caller can defer a backward pass's weight gradients and
  * hand them over in groups: the pixel split of a small layer then costs one full-chip set of f32 atomics per GROUP instead of per
  * layer (the dense-ASPP layers of bts.py:164-168).  Domain: bf16, Cout > 64, nphase == 1; BTS_ERR_UNSUPPORTED otherwise (call
