@@ -31,7 +31,7 @@ def family(name):
     if m:
         wr, wc, tm, tn = map(int, m.groups())
         return "conv_igemm_dma<bf16,%dx%d>" % (wr * tm * 32, wc * tn * 32)
-    m = re.match(r"conv_wgrad_ring<(\d), (\d)", n)
+    m = re.match(r"conv_wgrad_ring(?:_group)?<(\d), (\d)", n)      # the grouped launches are the same kernel body: one family
     if m:
         return "conv_wgrad_ring<bf16,%dx%d>" % (int(m.group(1)) * 64, int(m.group(2)) * 64)
     if n.startswith("conv_wgrad_tr"):
