@@ -413,7 +413,7 @@ def _two_rank_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from bts_amd.model import BtsModel, silog_loss
-        from bts_amd.parallel import GradAllReducer, broadcast_parameters
+        from bts_amd.parallel import BufferSync, GradAllReducer, broadcast_parameters
         params = NS(encoder="densenet121_bts", max_depth=80.0, dataset="kitti", bts_size=512)
         torch.manual_seed(50 + rank)                          # different init per rank: the broadcast must fix it
         model = BtsModel(params).to(DEV).train()
@@ -421,6 +421,9 @@ def _two_rank_worker(rank, world, port, q):
             if "conv0" in n or "norm" in n:
                 p.requires_grad = False
         broadcast_parameters(model)
+        # DDP's broadcast_buffers: the BatchNorm buffers of encoder and decoder become views of one flat tensor per dtype
+        sync = BufferSync(model)
+        assert len({b.untyped_storage().data_ptr() for b in model.buffers() if b.dtype == torch.float32}) == 1
         ref = BtsModel(params).to(DEV).train()
         ref.load_state_dict(model.state_dict())
         for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
@@ -438,6 +441,7 @@ def _two_rank_worker(rank, world, port, q):
         tail = sum(p.numel() * 4 for p in red.buckets[-1][1])
         assert tail <= (1 << 20), tail
         red.zero_grad()
+        sync()
         crit(model(x, focal)[4], gt, gt > 1.0).backward()
         log = list(red.launch_log)
         red.finish()
@@ -478,6 +482,24 @@ def _two_rank_worker(rank, world, port, q):
         mean = sum(parts) / world
         got = torch.cat([p.grad.flatten() for p in ref.decoder.parameters()]).cpu()
         assert l2rel(got, mean) < 1e-2
+        # the train step above moved the running statistics (through the views, by MIOpen's and this library's BatchNorm kernels)
+        # differently on the two ranks; after a sync every rank holds rank 0's, and an eval forward is identical everywhere
+        fb = torch.cat([b.flatten() for b in model.buffers() if b.dtype == torch.float32]).cpu()
+        both = [torch.zeros_like(fb) for _ in range(world)]
+        dist.all_gather(both, fb)
+        assert not torch.equal(both[0], both[1]), "rank-local batches should have moved the running statistics apart"
+        sync()
+        fb = torch.cat([b.flatten() for b in model.buffers() if b.dtype == torch.float32]).cpu()
+        dist.all_gather(both, fb)
+        assert torch.equal(both[0], both[1]) and torch.equal(fb, both[0])
+        model.eval()
+        xe = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(9)).to(DEV)
+        with torch.no_grad():
+            ye = model(xe, focal)[4].float().cpu()
+        outs = [torch.zeros_like(ye) for _ in range(world)]
+        dist.all_gather(outs, ye)
+        # (same parameters, same buffers, same input: equal up to MIOpen's per-process solver choice in the stock encoder)
+        assert torch.isfinite(ye).all() and l2rel(outs[0], outs[1]) < 1e-4, l2rel(outs[0], outs[1])
         q.put((rank, "ok"))
     except Exception as e:   # noqa: BLE001
         q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))

@@ -250,7 +250,7 @@ def test_grad_allreducer_one_shot_decoder_overlap_world2_gloo():
     assert all(r[1] == "ok" for r in res), res
 
 
-def _buffer_worker(rank, world, port, q):
+def _buffer_worker(rank, world, port, flatten, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -263,7 +263,13 @@ def _buffer_worker(rank, world, port, q):
         ref.load_state_dict(net.state_dict())
         ddp = nn.parallel.DistributedDataParallel(ref, find_unused_parameters=True)      # broadcast_buffers=True: bts_main.py:352
         red = GradAllReducer(net.parameters(), bucket_bytes=1 << 20)
-        sync = BufferSync(net)
+        sync = BufferSync(net, flatten=flatten)
+        if flatten:                                   # every float buffer is a view of ONE flat tensor: a sync is one broadcast
+            fl = [b for b in net.buffers() if b.dtype == torch.float32]
+            assert len({b.untyped_storage().data_ptr() for b in fl}) == 1 and len(sync.flat) == 2
+            sd = {k: v.clone() for k, v in net.state_dict().items()}
+            net.load_state_dict(sd)                    # in-place copies: the views survive a checkpoint load
+            assert len({b.untyped_storage().data_ptr() for b in net.buffers() if b.dtype == torch.float32}) == 1
         opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=0.1)
         opt_ref = torch.optim.SGD([p for p in ref.parameters() if p.requires_grad], lr=0.1)
         gen = torch.Generator().manual_seed(1000 + rank)                                   # rank-local batches
@@ -303,7 +309,8 @@ def _buffer_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_buffer_sync_matches_ddp_broadcast_buffers_world2_gloo():
+@pytest.mark.parametrize("flatten", [True, False], ids=["flat_views", "pack_unpack"])
+def test_buffer_sync_matches_ddp_broadcast_buffers_world2_gloo(flatten):
     """BatchNorm buffers under data parallelism: BufferSync() before each forward reproduces DistributedDataParallel's
     broadcast_buffers=True (the reference's setting): identical buffers after every train step, and an eval forward that uses
     rank 0's running statistics on every rank."""
@@ -311,7 +318,7 @@ def test_buffer_sync_matches_ddp_broadcast_buffers_world2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_buffer_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_buffer_worker, args=(r, world, port, flatten, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
