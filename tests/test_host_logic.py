@@ -130,3 +130,25 @@ def test_bench_synthetic_inputs_match_the_test_recipe():
         a = synth.synth_depth_gt(2, 32, 64, ds, torch.Generator().manual_seed(5))
         b = O.synth_depth_gt(2, 32, 64, ds, torch.Generator().manual_seed(5))
         assert torch.equal(a, b)
+
+
+def test_dual_and_group_predicates_follow_the_launchers():
+    """bts_amd/conv.py mirrors of the two round-4 launch forms: which layers of DenseNet161-BTS at the bench shape take them."""
+    from bts_amd.decoder import DecoderPlan
+    bf, f32 = torch.bfloat16, torch.float32
+    plan = DecoderPlan([96, 96, 192, 384, 2208], 512)
+    # conv1: 32 + 4 -> 32 channels: both data gradients from one pass over dz (bf16 only; f32 keeps two launches)
+    c1 = plan.layers["conv1.0"]
+    assert c1.dual_dgrad_ok(bf, 0, 1) and not c1.dual_dgrad_ok(f32, 0, 1)
+    assert not plan.layers["conv2.0"].dual_dgrad_ok(bf, 0, 2)            # dz has 64 channels: the weights do not fit the registers
+    small = DecoderPlan([64, 64, 128, 256, 1024], 128)                    # bts_size 128: conv1 is 8 + 4 -> 8, no full 32-channel block
+    assert not small.layers["conv1.0"].dual_dgrad_ok(bf, 0, 1)
+    # grouped weight gradients: the ten dense-ASPP layers and reduc8x8's 128 -> 128 layer (<= 16 tiles of the ring kernel), not the
+    # big ring layers, not the up-convolutions, not the LDS-halo-tile layers, nothing in f32
+    N, H, W = 8, 44, 152
+    want = ["daspp_%d.atrous_conv.aconv_sequence.%d" % (d, k) for d in (3, 6, 12, 18, 24) for k in (1, 4)] + ["reduc8x8.reduc.inter_128_128.0"]
+    assert all(plan.layers[n].wgrad_groupable(bf, N, H, W) for n in want)
+    for n, shape in (("conv4.0", (8, 44, 152)), ("daspp_conv.0", (8, 44, 152)), ("conv5.0", (8, 22, 76)), ("conv3.0", (8, 88, 304)),
+                     ("upconv4.conv", (8, 22, 76)), ("upconv3.conv", (8, 44, 152)), ("conv2.0", (8, 176, 608)), ("get_depth.0", (8, 352, 1216))):
+        assert not plan.layers[n].wgrad_groupable(bf, *shape), n
+    assert not any(L.wgrad_groupable(f32, N, H, W) for L in plan.layers.values())
