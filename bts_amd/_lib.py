@@ -20,7 +20,14 @@ ERRORS = {-1: "BTS_ERR_ARG", -2: "BTS_ERR_LAUNCH", -3: "BTS_ERR_UNSUPPORTED"}
 
 
 class BtsAmdError(RuntimeError):
-    pass
+    """code: the library's status (BTS_ERR_*) when the error comes from an entry point, else None."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
+
+
+ERR_UNSUPPORTED = -3
 
 
 class Seg(C.Structure):
@@ -160,11 +167,11 @@ def call(name, *args):
         e.record()
         profiler.ACTIVE.add(note[0], note[1], note[2], s, e, note[3], note[4])
         if rc != 0:
-            raise BtsAmdError("%s failed: %s (%d)" % (name, ERRORS.get(rc, "?"), rc))
+            raise BtsAmdError("%s failed: %s (%d)" % (name, ERRORS.get(rc, "?"), rc), rc)
         return rc
     rc = getattr(load(), name)(*args)
     if name not in _NO_CHECK and rc != 0:
-        raise BtsAmdError("%s failed: %s (%d)" % (name, ERRORS.get(rc, "?"), rc))
+        raise BtsAmdError("%s failed: %s (%d)" % (name, ERRORS.get(rc, "?"), rc), rc)
     return rc
 
 

@@ -272,10 +272,15 @@ class DecoderRun:
                         s.g = torch.empty(s.t.shape, dtype=self.dtype, device=dev)
                 done = set()
                 if len(segs) == 2 and not folds[1] and L.dual_dgrad_ok(dz.dtype, 0, 1):
-                    # both data gradients from one pass over dz (conv1: towards upconv1 and towards the depth-map slots)
-                    L.dgrad_dual(dz, self.packs.dgrad[(name, 0)], 0, segs[0].g, accs[0], segs[0].t if folds[0] else None,
-                                 self.packs.dgrad[(name, 1)], 1, segs[1].g, accs[1])
-                    done = {0, 1}
+                    # both data gradients from one pass over dz (conv1: towards upconv1 and towards the depth-map slots); a layout
+                    # outside the form's domain (the library answers BTS_ERR_UNSUPPORTED before launching anything) takes two launches
+                    try:
+                        L.dgrad_dual(dz, self.packs.dgrad[(name, 0)], 0, segs[0].g, accs[0], segs[0].t if folds[0] else None,
+                                     self.packs.dgrad[(name, 1)], 1, segs[1].g, accs[1])
+                        done = {0, 1}
+                    except BtsAmdError as e:
+                        if e.code != _lib.ERR_UNSUPPORTED:
+                            raise
                 for i, s in enumerate(segs):
                     if i not in done:
                         L.dgrad(dz, self.packs.dgrad[(name, i)], i, s.g, accs[i], s.t if folds[i] else None)
@@ -311,7 +316,13 @@ class DecoderRun:
             L, x, dz, dwp = items[0]
             L.wgrad_packed(x, dz, dwp)
         elif items:
-            ConvLayer.wgrad_group(items)
+            try:
+                ConvLayer.wgrad_group(items)
+            except BtsAmdError as e:           # outside the grouped form's domain (nothing was launched): layer by layer
+                if e.code != _lib.ERR_UNSUPPORTED:
+                    raise
+                for L, x, dz, dwp in items:
+                    L.wgrad_packed(x, dz, dwp)
 
     def conv_c1(self, name, x, out_scale, out_scale_n):
         """3x3 convolution to one channel + sigmoid * scale (get_depth, bts.py:193-194, 262-264) on the streaming kernels of
