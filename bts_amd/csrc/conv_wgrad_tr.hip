@@ -470,8 +470,8 @@ __global__ __launch_bounds__(WR* WC * 64) void conv_wgrad_ring_group(const Wgrad
         return;                                                                                                          \
     }
     // FIVE slots, not more: every slot is one inlined copy of the loop body, and with six the same two groups of the bench step ran
-    // 1.3-1.45x slower (272 / 248 us against 208 / 170 with five: gpurun r04k vs r04final2, same layers, same splits) -- the copies a
-    // CU's neighbours execute compete for the shared instruction cache
+    // 1.3-1.45x slower (272 / 248 us against 208 / 170 with five: gpurun r04k vs r04final2, same layers, same splits).  88 KB of code
+    // with five slots, 106 KB with six, 64 KB of instruction cache per CU pair: instruction fetch is the suspected (unverified) cause
     BTS_GROUP_CASE_(0) BTS_GROUP_CASE_(1) BTS_GROUP_CASE_(2) BTS_GROUP_CASE_(3) BTS_GROUP_CASE_(4)
     static_assert(WG_GROUP_MAX == 5, "one case per problem slot");
 #undef BTS_GROUP_CASE_

@@ -152,3 +152,52 @@ def test_dual_and_group_predicates_follow_the_launchers():
                      ("upconv4.conv", (8, 22, 76)), ("upconv3.conv", (8, 44, 152)), ("conv2.0", (8, 176, 608)), ("get_depth.0", (8, 352, 1216))):
         assert not plan.layers[n].wgrad_groupable(bf, *shape), n
     assert not any(L.wgrad_groupable(f32, N, H, W) for L in plan.layers.values())
+
+
+def test_deferred_weight_gradients_group_in_arrival_order(monkeypatch):
+    """DecoderRun._wgrad / _flush_wgrads: groupable layers leave five at a time in arrival order, a single leftover and every
+    non-groupable layer go through the per-layer call, and BTS_ERR_UNSUPPORTED from the grouped entry point falls back to it."""
+    from bts_amd import conv as conv_mod
+    from bts_amd import decoder as dec
+    from bts_amd._lib import ERR_UNSUPPORTED, BtsAmdError
+    log = []
+
+    class FakeLayer:
+        def __init__(self, name, groupable):
+            self.name, self.groupable = name, groupable
+
+        def wgrad_groupable(self, dtype, n, h, w):
+            return self.groupable
+
+        def wgrad_packed(self, x, dz, dwp):
+            log.append(("single", self.name))
+
+    class FakeT:
+        dtype = torch.bfloat16
+        shape = (8, 44, 152, 128)
+
+    fail = {"on": False}
+
+    def fake_group(items):
+        if fail["on"]:
+            raise BtsAmdError("bts_conv_wgrad_group failed: BTS_ERR_UNSUPPORTED (-3)", ERR_UNSUPPORTED)
+        log.append(("group", tuple(L.name for L, _, _, _ in items)))
+    monkeypatch.setattr(conv_mod.ConvLayer, "wgrad_group", staticmethod(fake_group))
+    run = object.__new__(dec.DecoderRun)
+    run.wgrad_pending = []
+    names = ["g%d" % i for i in range(7)]
+    for i, n in enumerate(names):
+        run._wgrad(FakeLayer(n, True), [FakeT()], FakeT(), None)
+        if i == 2:
+            run._wgrad(FakeLayer("big", False), [FakeT()], FakeT(), None)       # not groupable: launched at once, order kept
+    run._flush_wgrads()
+    assert log == [("single", "big"), ("group", tuple(names[:5])), ("group", tuple(names[5:]))], log
+    log.clear()
+    run._wgrad(FakeLayer("lonely", True), [FakeT()], FakeT(), None)
+    run._flush_wgrads()
+    assert log == [("single", "lonely")] and run.wgrad_pending == []
+    log.clear()
+    fail["on"] = True
+    for n in names[:5]:
+        run._wgrad(FakeLayer(n, True), [FakeT()], FakeT(), None)
+    assert log == [("single", n) for n in names[:5]], log                      # the group of five fell back, layer by layer
