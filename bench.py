@@ -67,7 +67,30 @@ def parse():
     ap.add_argument("--eager-steps", type=int, default=5, help="N=1: un-profiled eager steps timed after the replayed region (`eager` object: "
                     "the launch mode an N>1 run uses, so the driver's 1 -> N curve can be read like for like)")
     ap.add_argument("--force-dist", type=int, default=0, help=argparse.SUPPRESS)   # world-1 process group: exercises the N>1 path on one GPU
+    ap.add_argument("--plumbing-only", type=int, default=0, help=argparse.SUPPRESS)  # CPU test of the launch path: rendezvous + one all-reduce, no model
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this script spawns its own ranks (0 = pick a free one)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, one process per GPU, the way the
+    reference does (bts_main.py:600-602, `mp.spawn(main_worker, nprocs=ngpus_per_node)`) -- here by re-executing this script under
+    `torch.distributed.run` (same command line), so the plain command the driver uses for N = 1 works verbatim for N = 8.  Rendezvous
+    on 127.0.0.1 (the container hostname may not resolve).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL / cross-process tensors need it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def set_misc(model):
@@ -275,6 +298,7 @@ def parity_check(args, model, image, focal, dev):
                 out["%s_outputs_elem_p999" % tag] = float("%.3g" % max(elem(g, r, 0.999) for g, r in zip(got, ref)))
                 out["%s_outputs_elem_max" % tag] = float("%.3g" % max(elem(g, r, 1.0) for g, r in zip(got, ref)))
                 del dec
+            out["f64_arbiter"] = parity_arbiter_f64(args, O, bts, P, feats, focal, md, dev, elem)
         out["timed_dtype"] = args.dtype
         return out
     except Exception as e:   # noqa: BLE001  (reported, never fatal for the measurement)
@@ -282,6 +306,48 @@ def parity_check(args, model, image, focal, dev):
     finally:
         model.train(was_training)
         torch.cuda.empty_cache()
+
+
+def parity_arbiter_f64(args, O, bts, P, feats, focal, md, dev, elem):
+    """Which side of the f32 comparison carries the error?  ONE image of the bench batch: the oracle's formulas in f64 on the device
+    are the arbiter; the product's f32 decoder and torch's own f32 evaluation of the same formulas (the checker of the figures above)
+    are both measured against it, ELEMENT-WISE (|a - b| / |b|, maximum and 99.9th percentile over every pixel of the five outputs).
+    north_star's bound is 1e-4: `product_elem_max` is the figure it applies to.  `worst` names the output and pixel where the
+    product is furthest off and what torch's f32 evaluation does at the same pixel (a comparable error there = conditioning of the
+    formula at that pixel -- bts.py:146 divides by n1 u + n2 v + n3 --, not the kernel)."""
+    from types import SimpleNamespace as NS
+    f1 = [f[:1].contiguous() for f in feats]
+    fo = focal[:1]
+    with torch.backends.cudnn.flags(enabled=False):
+        P64 = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in P.items()}
+        ref64, _ = O.decoder_forward(P64, [f.double() for f in f1], fo.double(), md, args.dataset, True)
+        P32 = {k: v.clone() for k, v in P.items()}
+        ref32, _ = O.decoder_forward(P32, [f.clone() for f in f1], fo, md, args.dataset, True)
+    dec = bts(NS(max_depth=md, dataset=args.dataset, encoder=args.encoder, bts_size=512, decoder_dtype=torch.float32),
+              [f.shape[1] for f in f1], 512).to(dev)
+    dec.load_state_dict(P)
+    dec.train()
+    got = dec([f.clone() for f in f1], fo)
+    res = {"arbiter": "oracle formulas in f64 on the device, 1 image of the bench batch, train-mode BatchNorm",
+           "product_elem_max": float("%.3g" % max(elem(g, r, 1.0) for g, r in zip(got, ref64))),
+           "product_elem_p999": float("%.3g" % max(elem(g, r, 0.999) for g, r in zip(got, ref64))),
+           "torch_f32_elem_max": float("%.3g" % max(elem(g, r, 1.0) for g, r in zip(ref32, ref64))),
+           "torch_f32_elem_p999": float("%.3g" % max(elem(g, r, 0.999) for g, r in zip(ref32, ref64))),
+           "per_output_product_elem_max": [float("%.3g" % elem(g, r, 1.0)) for g, r in zip(got, ref64)],
+           "per_output_torch_f32_elem_max": [float("%.3g" % elem(g, r, 1.0)) for g, r in zip(ref32, ref64)]}
+    worst_i = max(range(5), key=lambda i: res["per_output_product_elem_max"][i])
+    g, r, t = got[worst_i].double().flatten(), ref64[worst_i].double().flatten(), ref32[worst_i].double().flatten()
+    rel = (g - r).abs() / r.abs().clamp_min(1e-30)
+    j = int(rel.argmax().item())
+    W = got[worst_i].shape[-1]
+    res["worst"] = {"output": worst_i, "pixel_yx": [j // W, j % W], "ref_value": float("%.6g" % r[j].item()),
+                    "product_rel_err": float("%.3g" % rel[j].item()),
+                    "torch_f32_rel_err_same_pixel": float("%.3g" % ((t[j] - r[j]).abs() / r[j].abs().clamp_min(1e-30)).item()),
+                    "pixels_over_1e-4": int((rel > 1e-4).sum().item()), "pixels": int(rel.numel())}
+    res["bound"] = 1e-4
+    res["met"] = bool(res["product_elem_max"] <= 1e-4)
+    del dec
+    return res
 
 
 def lpg_op_roofline(B, H, W, replays=5):
@@ -397,6 +463,20 @@ def infer_main(args):
     print(json.dumps(out), flush=True)
 
 
+def plumbing_main(args, world, rank):
+    """Launch-path check without a model (CPU test of `--gpus N`): process group from the environment, one all-reduce, the
+    barrier + max-over-ranks timing of the real line, rank 0 prints a line with the world it saw."""
+    dist.init_process_group(backend=args.backend, init_method="env://")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    dist.barrier()
+    el = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"plumbing": True, "n_gpus": world, "sum_ranks": t.item(), "max_elapsed": el.item(), "backend": args.backend}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -404,10 +484,17 @@ def main():
         return
     if args.mode == "infer":
         return infer_main(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))               # no launcher around us: become one (one rank per GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:                        # never print an n_gpus the command line did not ask for
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus (or without a launcher)"
+                 % (args.gpus, world))
     multi = world > 1 or bool(args.force_dist)
+    if args.plumbing_only:
+        return plumbing_main(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     local = local % torch.cuda.device_count()      # (plumbing tests run several ranks on one GPU over gloo)
     torch.cuda.set_device(local)                   # before the process group: RCCL binds the communicator to the current device
@@ -469,7 +556,7 @@ def main():
     image, focal, gt = make_batch(args, dev, 1234 + rank)
     if args.channels_last:
         image = image.contiguous(memory_format=torch.channels_last)
-    mask = gt > (1.0 if args.dataset == "kitti" else 0.1)
+    mask_thr = 1.0 if args.dataset == "kitti" else 0.1
     parity = parity_check(args, model, image, focal, dev) if (args.parity and world == 1 and rank == 0) else None
     total_steps = 50 * 1000
     gstep = [0]
@@ -485,6 +572,7 @@ def main():
             opt.zero_grad(set_to_none=not own_opt)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
             outs = net(image, focal)
+        mask = gt > mask_thr                         # built per step, as the reference does (bts_main.py:449-452)
         loss = crit(outs[4], gt, mask)
         loss.backward()
         if reducer is not None:
@@ -500,6 +588,7 @@ def main():
         reducer.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
             outs = net(image, focal)
+        mask = gt > mask_thr
         loss = crit(outs[4], gt, mask)
         with reducer.no_sync():
             loss.backward()

@@ -165,7 +165,8 @@ def call(name, *args):
         s.record()
         rc = getattr(load(), name)(*args)
         e.record()
-        profiler.ACTIVE.add(note[0], note[1], note[2], s, e, note[3], note[4])
+        if rc != ERR_UNSUPPORTED:      # nothing was launched: the caller retries with other launches, which record their own work
+            profiler.ACTIVE.add(note[0], note[1], note[2], s, e, note[3], note[4])
         if rc != 0:
             raise BtsAmdError("%s failed: %s (%d)" % (name, ERRORS.get(rc, "?"), rc), rc)
         return rc

@@ -25,20 +25,41 @@ def _hipcc():
     return "hipcc"
 
 
-def _stale(out, deps):
-    if not os.path.exists(out):
-        return True
-    t = os.path.getmtime(out)
-    return any(os.path.getmtime(d) > t for d in deps)
+MANIFEST = os.path.join(LIBDIR, "manifest.json")
+
+
+def _sha(paths, extra=""):
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(hashlib.sha256(f.read()).digest())
+    return h.hexdigest()
+
+
+def _md5(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.md5(f.read()).hexdigest()
 
 
 def build_library(force=False, verbose=True, jobs=None):
+    """Objects and library are rebuilt by CONTENT, not by mtime: `lib/manifest.json` (git-ignored, travels with the binaries) records
+    the sha256 of (source + headers + flags) every object was compiled from and the md5 of the linked library.  A snapshot that
+    carries binaries of OTHER sources (mtimes are meaningless after a copy) is rebuilt; binaries of exactly these sources are reused."""
+    import json
     os.makedirs(LIBDIR, exist_ok=True)
-    objs, todo = [], []
+    try:
+        with open(MANIFEST) as f:
+            man = json.load(f)
+    except (OSError, ValueError):
+        man = {}
+    objs, todo, want = [], [], {}
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + HEADERS):
+        want[src] = _sha([s] + HEADERS, " ".join(FLAGS))
+        if force or not os.path.exists(o) or man.get("objects", {}).get(src) != want[src]:
             todo.append([_hipcc()] + FLAGS + ["-c", s, "-o", o])
         objs.append(o)
     for stale in os.listdir(LIBDIR):                    # objects of translation units that no longer exist
@@ -53,12 +74,26 @@ def build_library(force=False, verbose=True, jobs=None):
             subprocess.check_call(cmd)
         with ThreadPoolExecutor(max_workers=jobs or min(len(todo), os.cpu_count() or 1)) as ex:
             list(ex.map(run, todo))
-    if force or _stale(LIB, objs):
+    if force or todo or not os.path.exists(LIB) or man.get("library_md5") != _md5(LIB) or man.get("objects") != want:
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    with open(MANIFEST, "w") as f:
+        json.dump({"objects": want, "library_md5": _md5(LIB), "flags": FLAGS}, f, indent=1)
     return LIB
+
+
+def verify_library():
+    """True when bts_amd/lib/libbts_amd.so is the library the manifest says was linked from the CURRENT sources."""
+    import json
+    try:
+        with open(MANIFEST) as f:
+            man = json.load(f)
+    except (OSError, ValueError):
+        return False
+    want = {src: _sha([os.path.join(CSRC, src)] + HEADERS, " ".join(FLAGS)) for src in SOURCES}
+    return os.path.exists(LIB) and man.get("objects") == want and man.get("library_md5") == _md5(LIB)
 
 
 if __name__ == "__main__":

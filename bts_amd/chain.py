@@ -99,8 +99,9 @@ BWD_SUPPORTED = {(64, 2), (32, 1), (64, 4), (32, 2), (16, 1), (32, 4), (16, 2), 
 
 
 def bwd_supported(c0, same_first, k, dtype):
-    """Shapes with a fused recompute backward (csrc/lpg_chain.hip::lpg_chain_bwd_kernel)."""
-    return dtype == torch.bfloat16 and not same_first and (c0, k) in BWD_SUPPORTED
+    """Shapes with a fused recompute backward (csrc/lpg_chain.hip::lpg_chain_bwd_kernel, bf16; lpg_chain_bwd_f32_kernel, f32: the
+    parity configuration trains through the same fused kernel design the bf16 headline times)."""
+    return dtype in (torch.bfloat16, torch.float32) and not same_first and (c0, k) in BWD_SUPPORTED
 
 
 def pack_chain_t(weights, dtype):

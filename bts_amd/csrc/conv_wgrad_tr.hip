@@ -754,24 +754,31 @@ int launch_wgrad_ring_group(const ConvK* ks, int n, hipStream_t st) {
     }
     // chunks per workgroup: the smallest count (>= 8) with which the whole group fits the chip in ONE round -- a 257th workgroup
     // would run alone behind the other 256
-    long per_wg = ceil_div(work, bts_cu_count());
-    if (per_wg < 8) per_wg = 8;
+    // (the workgroup count is monotone non-increasing in per_wg: bisection between the even split and "every problem unsplit")
     int total = 0;
-    for (int iter = 0; iter < 4096; ++iter, ++per_wg) {
+    auto plan = [&](long per_wg) {
         total = 0;
         for (int i = 0; i < n; ++i) {
             ConvK& k = g.p[i];
-            int splits = ceil_div(k.nchunks, per_wg);
+            int splits = (int)ceil_div((long)k.nchunks, per_wg);
             if (splits < 1) splits = 1;
             k.chunks_per_split = ceil_div(k.nchunks, splits);
             splits = ceil_div(k.nchunks, k.chunks_per_split);
             g.first[i] = total;
             total += k.n_co_tiles * k.n_col_tiles * splits;
         }
-        bool unsplit = true;                                  // every problem down to one split: nothing left to merge
-        for (int i = 0; i < n; ++i) unsplit = unsplit && g.p[i].chunks_per_split >= g.p[i].nchunks;
-        if (total <= bts_cu_count() || unsplit) break;
+        return total;
+    };
+    long lo = ceil_div(work, (long)bts_cu_count());
+    if (lo < 8) lo = 8;
+    long hi = lo;
+    for (int i = 0; i < n; ++i) hi = g.p[i].nchunks > hi ? g.p[i].nchunks : hi;      // per_wg = hi: nothing is split
+    if (plan(hi) > bts_cu_count()) return BTS_ERR_UNSUPPORTED;      // the unsplit tiles alone exceed one round: not this kernel's domain
+    while (lo < hi) {
+        const long mid = (lo + hi) / 2;
+        if (plan(mid) <= bts_cu_count()) hi = mid; else lo = mid + 1;
     }
+    plan(lo);
     for (int i = n; i <= WG_GROUP_MAX; ++i) g.first[i] = total;
     g.n = n;
     static DynLdsCache lds_set;

@@ -642,6 +642,195 @@ __global__ __launch_bounds__(256, (C0 >= 128 ? 1 : 2)) void lpg_chain_bwd_kernel
     BwdLayer<C0, NOUT, KUP, true, 0, NTOT>::reduce(dw, (float*)scr0, a, 0, tid);
 }
 
+// ---- the same recompute backward in f32 (the parity configuration: bts.py:83-146 under autograd, 1e-4) ------------------------
+// v_mfma_f32_32x32x2_f32 everywhere: exact f32 FMA chains.  The register image of an activation set is Act<F32>::Regs<C>:
+// v[4u + j] = channel 8u + 4g + j of the lane's cell -- which is ALSO the accumulator order of a 32x32 tile (row = (r & 3) + 8 (r >> 2)
+// + 4 g: u = 4 tm + (r >> 2), j = r & 3), so layers chain forwards and backwards with no permutation at all.  The weight gradient
+// contracts over cells two at a time (A[i][k]: lane = (channel i, cell k = lane >> 5)): dz and a_in are written cell-major to a
+// per-wave LDS scratch with 16-byte stores (rows of one cell, pitch C + 4 floats) and read back as one conflict-free ds_read_b32 per
+// operand and cell pair.  Same HBM traffic as the bf16 kernel at twice the bytes per element; the MFMAs run at the f32 rate.
+template <int C>
+constexpr int cell_pitch_f32() { return (C < 8 ? 8 : C) + 4; }          // floats
+template <int C>
+__device__ __forceinline__ void store_cells_f32(const Act<F32>::Regs<C>& a, float* rows, int cl, int g) {
+    constexpr int KU = (C < 8 ? 8 : C) / 8, P = cell_pitch_f32<C>();
+    float* base = rows + cl * P + 4 * g;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) *(f32x4_t*)(base + 8 * u) = f32x4_t{a.v[4 * u], a.v[4 * u + 1], a.v[4 * u + 2], a.v[4 * u + 3]};
+}
+// per-wave scratch in floats: dz rows + a_in rows of the widest (= first) layer, plus slack: fragment reads of a narrow layer run
+// up to 31 floats past its last row (they only feed weight-gradient rows / columns that are never written out)
+template <int C, int NOUT>
+constexpr int bwd_scr_floats() {
+    constexpr int cout = C > 8 ? C / 2 : NOUT;
+    return 32 * (cell_pitch_f32<cout>() + cell_pitch_f32<C>()) + 64;
+}
+
+template <int C, int NOUT, int KUP, int T0, int NTOT>
+struct BwdLayerF {
+    static constexpr int COUT = C > 8 ? C / 2 : NOUT;
+    static constexpr int TMO = (COUT + 31) / 32, TNI = (C + 31) / 32;
+    static constexpr int NVO = (COUT < 8 ? 8 : COUT) / 2;
+    using RegsIn = Act<F32>::Regs<C>;
+    using RegsOut = Act<F32>::Regs<COUT>;
+
+    __device__ static __forceinline__ void run(const RegsIn& a_in, const char* wf, const char* wt, float* scr, const TileCtx& t,
+                                               f32x16_t (&dw)[NTOT], f32x16_t (&dA)[TNI]) {
+        RegsOut dz;
+        if constexpr (C > 8) {
+            RegsOut a_out;
+            dense_elu<F32, C, COUT>(a_in, wf, t.lane, a_out);
+            f32x16_t dAo[TMO];
+            BwdLayerF<COUT, NOUT, KUP, T0 + TMO * TNI, NTOT>::run(
+                a_out, wf + layer_bytes<F32, C, COUT>(), wt + layer_bytes<F32, COUT, C>(), scr, t, dw, dAo);
+#pragma unroll
+            for (int m = 0; m < NVO; ++m)                       // dz = dA_out * elu'(z), from the ELU output: y > 0 ? 1 : y + 1 (= e^z)
+                dz.v[m] = dAo[m >> 4][m & 15] * elu_grad_from_out(a_out.v[m]);
+        } else {
+            f32x16_t acc;
+            dense_tile<C>(a_in, wf, t.lane, 0, acc);
+            float gr[3];
+            head_bwd<KUP>(acc, t, gr);
+#pragma unroll
+            for (int m = 0; m < NVO; ++m) dz.v[m] = 0.f;
+            if (t.g == 0) { dz.v[0] = gr[0]; dz.v[1] = gr[1]; dz.v[2] = gr[2]; }
+        }
+        // weight gradient: dW[co][ci] += sum_cells dz[co][cell] * a_in[ci][cell]
+        constexpr int ZP = cell_pitch_f32<COUT>(), AP = cell_pitch_f32<C>();
+        float* zr = scr;
+        float* ar = scr + 32 * ZP;
+        store_cells_f32<COUT>(dz, zr, t.cl, t.g);
+        store_cells_f32<C>(a_in, ar, t.cl, t.g);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): this wave's rows are in LDS
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {                             // cells 2 s + g
+            float bv[TNI];
+#pragma unroll
+            for (int tn = 0; tn < TNI; ++tn) bv[tn] = ar[(2 * s + t.g) * AP + 32 * tn + t.cl];
+#pragma unroll
+            for (int tm = 0; tm < TMO; ++tm) {
+                const float av = zr[(2 * s + t.g) * ZP + 32 * tm + t.cl];
+#pragma unroll
+                for (int tn = 0; tn < TNI; ++tn)
+                    dw[T0 + tm * TNI + tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[tn], dw[T0 + tm * TNI + tn], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // input gradient: dA_in = W^T dz
+#pragma unroll
+        for (int tn = 0; tn < TNI; ++tn) dense_tile<COUT>(dz, wt, t.lane, tn, dA[tn]);
+    }
+
+    template <int NW>
+    __device__ static __forceinline__ void reduce(f32x16_t (&dw)[NTOT], float* red, const ChainBwdK& a, int layer, int tid) {
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int tm = 0; tm < TMO; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TNI; ++tn) {
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = dw[T0 + tm * TNI + tn][r];
+                __syncthreads();
+                float* dst = a.dw[layer];
+                const int ld = a.dw_ld[layer];
+                for (int idx = tid; idx < 1024; idx += 64 * NW) {
+                    const int r = idx >> 6, l = idx & 63;
+                    const int co = 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ci = 32 * tn + (l & 31);
+                    if (co < COUT && ci < C) {
+                        float v = red[idx];
+#pragma unroll
+                        for (int w2 = 1; w2 < NW; ++w2) v += red[w2 * 1024 + idx];
+                        atomicAdd(dst + (size_t)co * ld + ci, v);
+                    }
+                }
+            }
+        if constexpr (C > 8) BwdLayerF<COUT, NOUT, KUP, T0 + TMO * TNI, NTOT>::template reduce<NW>(dw, red, a, layer + 1, tid);
+    }
+};
+
+// C0 = 128: two waves per workgroup (the f32 fragments of both directions, 91 KiB, + 26 KiB of scratch per wave), one wave per SIMD
+template <int C0, int KUP, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void lpg_chain_bwd_f32_kernel(const ChainBwdK a) {
+    constexpr int NOUT = KUP == 1 ? 1 : 3;
+    constexpr int NTOT = bwd_dw_tiles<C0, NOUT>();
+    constexpr int SF = bwd_scr_floats<C0, NOUT>();
+    constexpr int TN0 = (C0 + 31) / 32;
+    constexpr int SCR_FLOATS = NW * SF > NW * 1024 ? NW * SF : NW * 1024;       // the cross-wave reduction needs 1024 floats per wave
+    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* wf = wlds;
+    char* wt = wlds + a.wf_bytes;
+    float* scr0 = (float*)(wt + a.wt_bytes);
+    for (int i = tid * 16; i < a.wf_bytes; i += 64 * NW * 16) *(u32x4_t*)(wf + i) = *(const u32x4_t*)(a.wf + i);
+    for (int i = tid * 16; i < a.wt_bytes; i += 64 * NW * 16) *(u32x4_t*)(wt + i) = *(const u32x4_t*)(a.wt + i);
+    for (int i = tid * 4; i < SCR_FLOATS; i += 64 * NW * 4) *(f32x4_t*)(scr0 + i) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    float* scr = scr0 + wave * SF;
+    const int g = lane >> 5, cl = lane & 31;
+    const long ntiles = (a.cells + 31) / 32;
+    f32x16_t dw[NTOT];
+#pragma unroll
+    for (int i = 0; i < NTOT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw[i][r] = 0.f;
+    const long tstep = (long)gridDim.x * NW;
+    for (long tile = (long)blockIdx.x * NW + wave; tile < ntiles; tile += tstep) {
+        TileCtx t;
+        t.gout = a.gout; t.cell = tile * 32 + cl; t.ok = t.cell < a.cells; t.w_cells = a.w_cells;
+        t.lane = lane; t.cl = cl; t.g = g; t.max_depth = a.max_depth;
+        Act<F32>::Regs<C0> in;
+        load_input_f32<C0>(a.x, (size_t)t.cell, a.x_stride, t.ok, g, in);
+        f32x16_t dA[TN0];
+        BwdLayerF<C0, NOUT, KUP, 0, NTOT>::run(in, wf, wt, scr, t, dw, dA);
+        if (t.ok) {                                        // dx: 4 consecutive channels per accumulator quad = one 16-byte access
+            float* px = (float*)a.dx + (size_t)t.cell * a.dx_stride;
+            const float* xx = (const float*)a.x + (size_t)t.cell * a.x_stride;
+#pragma unroll
+            for (int tn = 0; tn < TN0; ++tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = 32 * tn + 8 * q + 4 * g;
+                    if (ch < C0) {
+                        f32x4_t v = {dA[tn][4 * q], dA[tn][4 * q + 1], dA[tn][4 * q + 2], dA[tn][4 * q + 3]};
+                        if (a.dx_accumulate) v += *(const f32x4_t*)(px + ch);
+                        if (a.fold_elu) {
+                            const f32x4_t xv = *(const f32x4_t*)(xx + ch);
+                            v[0] *= elu_grad_from_out(xv[0]); v[1] *= elu_grad_from_out(xv[1]);
+                            v[2] *= elu_grad_from_out(xv[2]); v[3] *= elu_grad_from_out(xv[3]);
+                        }
+                        *(f32x4_t*)(px + ch) = v;
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    BwdLayerF<C0, NOUT, KUP, 0, NTOT>::template reduce<NW>(dw, scr0, a, 0, tid);
+}
+
+template <int C0, int KUP>
+int launch_chain_bwd_f32(const ChainBwdK& k, hipStream_t st) {
+    constexpr int NOUT = KUP == 1 ? 1 : 3;
+    constexpr int NW = C0 >= 128 ? 2 : 4;
+    constexpr int SF = bwd_scr_floats<C0, NOUT>();
+    constexpr int SCR_FLOATS = NW * SF > NW * 1024 ? NW * SF : NW * 1024;
+    auto kern = lpg_chain_bwd_f32_kernel<C0, KUP, NW>;
+    const int lds = k.wf_bytes + k.wt_bytes + SCR_FLOATS * 4;
+    if (lds > 160 * 1024) return BTS_ERR_UNSUPPORTED;
+    static DynLdsCache lds_set;
+    if (ensure_dyn_lds((const void*)kern, lds, lds_set) != BTS_OK) return BTS_ERR_LAUNCH;
+    const long ntiles = (k.cells + 31) / 32;
+    long blocks = (ntiles + NW - 1) / NW;
+    int per_cu = C0 >= 64 ? 1 : 2;                   // the f32 chains keep 13 / 7 / 4 accumulator tiles + f32 activations per wave
+    if (per_cu > 160 * 1024 / lds) per_cu = 160 * 1024 / lds;
+    if (per_cu < 1) per_cu = 1;
+    if (blocks > (long)bts_cu_count() * per_cu) blocks = (long)bts_cu_count() * per_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW), (size_t)lds, st, k);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
 template <int C0, int KUP>
 int launch_chain_bwd(const ChainBwdK& k, hipStream_t st) {
     constexpr int NOUT = KUP == 1 ? 1 : 3;
@@ -688,8 +877,10 @@ extern "C" int bts_lpg_chain_bwd(const void* x, int dtype, int x_stride, int c0,
     BTS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_frags & 15) == 0 && ((uintptr_t)wt_frags & 15) == 0);
     BTS_CHECK_ARG(((uintptr_t)grad_x & 7) == 0 && ((uintptr_t)grad_out & 15) == 0 && n_layers >= 2 && n_layers <= 6);
     BTS_CHECK_ARG(cells % ((long)in_h * in_w) == 0);
-    if (dtype != BTS_BF16) return BTS_ERR_UNSUPPORTED;      // f32 (parity mode) trains layer by layer
-    BTS_CHECK_ARG(x_stride % 8 == 0 && x_stride >= c0 && grad_x_stride % 4 == 0 && grad_x_stride >= c0);
+    BTS_CHECK_ARG(dtype == BTS_F32 || dtype == BTS_BF16);
+    const bool f32 = dtype == BTS_F32;
+    BTS_CHECK_ARG(x_stride % (f32 ? 4 : 8) == 0 && x_stride >= c0 && grad_x_stride % 4 == 0 && grad_x_stride >= c0);
+    if (f32) BTS_CHECK_ARG(((uintptr_t)grad_x & 15) == 0);
     int expect = 1;
     for (int c = c0; c > 8; c >>= 1) ++expect;
     BTS_CHECK_ARG(n_layers == expect);
@@ -706,7 +897,7 @@ extern "C" int bts_lpg_chain_bwd(const void* x, int dtype, int x_stride, int c0,
     }
     k.cells = cells; k.h = in_h; k.w_cells = in_w; k.max_depth = max_depth;
     hipStream_t st = (hipStream_t)stream;
-#define CASE(C, K) if (c0 == C && upratio == K) return launch_chain_bwd<C, K>(k, st)
+#define CASE(C, K) if (c0 == C && upratio == K) return f32 ? launch_chain_bwd_f32<C, K>(k, st) : launch_chain_bwd<C, K>(k, st)
     CASE(64, 2); CASE(32, 1);               // bts_size 512: reduc2x2, reduc1x1 (bts.py:186, 190)
     CASE(64, 4); CASE(32, 2); CASE(16, 1);  // bts_size 256
     CASE(32, 4); CASE(16, 2);               // bts_size 128

@@ -303,7 +303,7 @@ class DecoderRun:
 
     def _wgrad(self, L, x, dz, dwp):
         N, Hx, Wx, _ = x[0].shape
-        if not L.wgrad_groupable(dz.dtype, N, Hx, Wx):
+        if dz.dtype != x[0].dtype or not L.wgrad_groupable(x[0].dtype, N, Hx, Wx):      # keyed like _wgrad_desc: the inputs' dtype
             L.wgrad_packed(x, dz, dwp)
             return
         self.wgrad_pending.append((L, x, dz, dwp))
@@ -609,9 +609,13 @@ class DecoderRun:
         dev = next(iter(self.packs.fwd.values())).device
         self.packs.pack_dgrad()
         self.dwp_arena = torch.zeros(self.packs.dwp_total, dtype=torch.float32, device=dev)     # one memset for every layer
-        for fn in reversed(self.tape):
-            fn()
-        self._flush_wgrads()
+        try:
+            for fn in reversed(self.tape):
+                fn()
+            self._flush_wgrads()
+        finally:
+            # an error mid-pass must not leave (layer, inputs, dz, slot-of-THIS-arena) tuples behind for a retried backward to flush
+            self.wgrad_pending = []
         self.tape = []
         gw_arena = torch.empty(self.packs.gw_total, dtype=torch.float32, device=dev)
         self.packs.unpack_all(self.dwp_arena, gw_arena)

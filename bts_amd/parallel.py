@@ -163,8 +163,22 @@ def broadcast_parameters(module, src=0, process_group=None):
     """Rank-0 -> all broadcast of parameters and buffers at start-up (what DDP's constructor does)."""
     if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
         return
+    # one broadcast per (dtype, device) over a flat copy instead of ~2 000 small ones (DenseNet161-BTS: 1 200 parameters + 1 450 buffers)
+    by_key, seen = {}, set()
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=process_group)
+        if id(t) in seen:
+            continue
+        seen.add(id(t))
+        by_key.setdefault((t.dtype, t.device), []).append(t.data)
+    with torch.no_grad():
+        for ts in by_key.values():
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src, group=process_group)
+            off = 0
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
 
 
 class BufferSync:
@@ -189,6 +203,8 @@ class BufferSync:
         self.src, self.group = src, process_group
         self.active = dist.is_initialized() and dist.get_world_size(process_group) > 1
         self.flat = []          # flatten: [flat tensor]; else: [[buffers]]
+        self._views = []        # (module, buffer name, data_ptr of the view) -- checked before every sync
+        self._module = module
         self.flattened = bool(flatten)
         by_key = {}
         for m in module.modules():
@@ -213,11 +229,26 @@ class BufferSync:
                     off += b.numel()
                 for m, name, b in entries:
                     m._buffers[name] = seen[id(b)]
+                    self._views.append((m, name, seen[id(b)].data_ptr()))
                 self.flat.append(flat)
+
+    def _views_intact(self):
+        """The modules must still point at the views: `module.to(dtype)` / `.cuda()` / `load_state_dict(assign=True)` /
+        `register_buffer` after construction silently replace them, and a broadcast of the flat tensor would then sync nothing."""
+        return all(m._buffers.get(name) is not None and m._buffers[name].data_ptr() == ptr for m, name, ptr in self._views)
 
     def __call__(self):
         if not self.active:
             return
+        if self.flattened and not self._views_intact():
+            # something re-bound the buffers after construction: fall back to gather / broadcast / scatter over the live ones
+            self.flattened = False
+            by_key = {}
+            for m in self._module.modules():
+                for name, b in m._buffers.items():
+                    if b is not None:
+                        by_key.setdefault((b.dtype, b.device), []).append(b)
+            self.sets = list(by_key.values())
         with torch.no_grad():
             if self.flattened:
                 for flat in self.flat:

@@ -109,7 +109,8 @@ int bts_lpg_chain_fwd(const void* x, int dtype, int x_stride, int c0, int same_f
                       int w_bytes, float* out, long cells, int in_h, int in_w, int upratio, float max_depth,
                       bts_stream_t stream);
 
-/* Training backward of the same fused head for the narrow halving chains (c0 <= 64, bf16): recomputes the chain
+/* Training backward of the same fused head for the halving chains (c0 <= 128; bf16, and f32 = the parity configuration, on
+ * v_mfma_f32_32x32x2_f32: exact f32 FMA chains, 1e-4 against autograd): recomputes the chain
  * from x, differentiates sigmoid / plane / normalise / LPG (or the reduc1x1 sigmoid) in registers, and produces in
  * ONE pass the gradient of x and of every 1x1 weight of the chain -- what autograd does layer by layer through
  * bts.py:83-122, 124-146 (parity target: PyTorch autograd of the reference module).
@@ -117,7 +118,8 @@ int bts_lpg_chain_fwd(const void* x, int dtype, int x_stride, int c0, int same_f
  *   grad_out   f32: [B][h*k][w*k] gradient of the depth map (k = 8/4/2) or [cells] of the sigmoid map (k = 1)
  *   grad_x     [cells][grad_x_stride] in `dtype`; accumulate != 0 adds to its contents
  *   grad_w     n_layers pointers: f32 [Cout_l][grad_w_ld[l]], accumulated with atomics (caller zeroes)
- * Returns BTS_ERR_UNSUPPORTED for f32 or chain shapes without an instantiation (caller runs the layer-wise path).  * x_is_elu_output: x is the ELU output of the producing convolution and this call COMPLETES its gradient (it is the last
+ * Returns BTS_ERR_UNSUPPORTED for chain shapes without an instantiation (caller runs the layer-wise path).
+ * x_is_elu_output: x is the ELU output of the producing convolution and this call COMPLETES its gradient (it is the last
  * writer): the value stored is (dx [+ old]) * ELU'(x), so that convolution's backward needs no activation-derivative pass. */
 int bts_lpg_chain_bwd(const void* x, int dtype, int x_stride, int c0, const void* w_frags, int w_bytes,
                       const void* wt_frags, int wt_bytes, const float* grad_out, void* grad_x, int grad_x_stride,
@@ -210,6 +212,10 @@ typedef struct {
     void* y2;
     int32_t Cout2, y2_stride, accumulate2;
 } bts_conv_desc_t;
+/* The descriptor MUST be zero-initialised before it is filled (`bts_conv_desc_t d = {0};` / memset): optional fields (fold_elu_y,
+ * w2 / y2 / Cout2 / y2_stride / accumulate2, out_scale_n) are tested against NULL / 0, and fields added at the END of the struct
+ * in later ABI versions (bts_abi_version()) default to "absent" only that way.  A caller compiled against an older header must
+ * check bts_abi_version() == the version of its header before passing the struct. */
 
 int bts_conv_fwd(const bts_conv_desc_t* d, bts_stream_t stream);
 

@@ -22,6 +22,26 @@ def rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
+def bf16_excess(a, b, half_ulps=2.0):
+    """ELEMENT-WISE check of a result that was STORED as bf16 against the f32 reference computed from identical (bf16-rounded)
+    operands: a correct kernel rounds the f32-accumulated value once, so |a - b| <= 2^-9 |b| per element; `half_ulps` = 2 allows
+    2^-8 |b| (one more half-ulp for accumulation order).  Returns max(|a - b| - half_ulps * 2^-9 * |b|) / max|b| -- the part of the
+    worst element's error that rounding cannot explain, relative to the tensor's scale; a dropped tap or border row is O(1e-1)."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    ex = ((a - b).abs() - half_ulps * 2.0 ** -9 * b.abs()).clamp_min(0.0).max()
+    return (ex / b.abs().max().clamp_min(1e-30)).item()
+
+
+def bf16_bad(a, b, half_ulps=2.0, atol_rel=1e-4):
+    """number of elements outside |a - b| <= half_ulps * 2^-9 |b| + atol_rel * max|b| (for results behind a ReLU mask: an input
+    within f32 rounding of zero may take the other branch in two correct evaluations -- a handful of elements per million)"""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return int(((a - b).abs() > half_ulps * 2.0 ** -9 * b.abs() + atol_rel * b.abs().max()).sum().item())
+
+
+BF16_ATOL = 1e-4      # of max|b|: f32 accumulation-order noise of a K <= 10^4 contraction is ~1e-6 of it
+
+
 def load(golden_dir, name):
     return np.load("%s/%s.npz" % (golden_dir, name))
 
@@ -166,7 +186,6 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
     from bts_amd._lib import ACT_NONE
     name, cout, segc, kk, dil, up, (N, H, W) = case
     v = 4 if dt == torch.float32 else 8
-    tol = 1e-4 if dt == torch.float32 else 2e-2
     gen = torch.Generator().manual_seed(sum(map(ord, name)))
     cin = sum(segc)
     xs = [torch.randn(N, c, H, W, generator=gen) for c in segc]
@@ -194,8 +213,14 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
     out = torch.zeros(N, Ho, Wo, cp, dtype=dt, device=DEV)
     L.forward(segs, L.pack_fwd(wd_dev, dt), out, ACT_NONE)
     torch.cuda.synchronize()
-    e = rel(out[..., :cout].float().permute(0, 3, 1, 2), ref)
-    print("%s %s fwd rel %.3e" % (name, dt, e))
+    bf = dt == torch.bfloat16
+
+    def err(a, b, half_ulps=2.0):
+        """f32: max-norm relative error (bar 1e-4); bf16-stored results: the element-wise excess over bf16 rounding (bar BF16_ATOL)"""
+        return bf16_excess(a, b, half_ulps) if bf else rel(a, b)
+    tol = BF16_ATOL if bf else 1e-4
+    e = err(out[..., :cout].float().permute(0, 3, 1, 2), ref)
+    print("%s %s fwd err %.3e (max-norm %.3e)" % (name, dt, e, rel(out[..., :cout].float().permute(0, 3, 1, 2), ref)))
     assert e < tol, "fwd"
     assert out[..., cout:].abs().max().item() == 0.0 if cp > cout else True
 
@@ -203,28 +228,29 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
     for i, (x, c) in enumerate(zip(xs_r, segc)):
         gx = torch.empty_like(segs[i])
         L.dgrad(dz, L.pack_dgrad(wd_dev, dt, i), i, gx, False)
-        e = rel(gx[..., :c].float().permute(0, 3, 1, 2), x.grad)
-        print("%s %s dgrad seg%d rel %.3e" % (name, dt, i, e))
+        e = err(gx[..., :c].float().permute(0, 3, 1, 2), x.grad)
+        print("%s %s dgrad seg%d err %.3e" % (name, dt, i, e))
         assert e < tol, "dgrad seg %d" % i
-        # accumulate mode adds on top
+        # accumulate mode adds on top (bf16: the first result was rounded, the sum is rounded again: 3 half-ulps of 2 g)
         L.dgrad(dz, L.pack_dgrad(wd_dev, dt, i), i, gx, True)
-        assert rel(gx[..., :c].float().permute(0, 3, 1, 2), 2 * x.grad) < 2 * tol
+        assert err(gx[..., :c].float().permute(0, 3, 1, 2), 2 * x.grad, 3.0) < 2 * tol
         # ELU-derivative fold (bts_conv_desc_t::fold_elu_y): the launch that completes the gradient of an ELU output takes it
         # through the ELU -- (result [+ old]) * (y > 0 ? 1 : y + 1) -- in every kernel's epilogue, written and accumulated
         yv = _nhwc(torch.randn(x.shape, generator=gen), dt, v)
         fac = torch.where(yv.float() > 0, torch.ones_like(yv, dtype=torch.float32), yv.float() + 1.0)[..., :c].permute(0, 3, 1, 2).cpu()
         gf = torch.empty_like(segs[i])
         L.dgrad(dz, L.pack_dgrad(wd_dev, dt, i), i, gf, False, yv)
-        assert rel(gf[..., :c].float().permute(0, 3, 1, 2), x.grad * fac) < tol, "fold seg %d" % i
+        assert err(gf[..., :c].float().permute(0, 3, 1, 2), x.grad * fac) < tol, "fold seg %d" % i
         base = _nhwc(torch.randn(x.shape, generator=gen), dt, v)
         ga = base.clone()
         L.dgrad(dz, L.pack_dgrad(wd_dev, dt, i), i, ga, True, yv)
         want = (x.grad + base[..., :c].float().permute(0, 3, 1, 2).cpu()) * fac
-        assert rel(ga[..., :c].float().permute(0, 3, 1, 2), want) < 2 * tol, "fold+acc seg %d" % i
+        assert err(ga[..., :c].float().permute(0, 3, 1, 2), want) < 2 * tol, "fold+acc seg %d" % i
+    # the weight gradient is f32 on both paths, from identical (bf16-rounded) operands: f32 accumulation order is all that differs
     gw = L.wgrad(segs, dz)
     e = rel(gw, w_r.grad)
     print("%s %s wgrad rel %.3e" % (name, dt, e))
-    assert e < (1e-4 if dt == torch.float32 else 3e-2), "wgrad"
+    assert e < 1e-4, "wgrad"
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
@@ -237,7 +263,6 @@ def test_conv3x3_c1_streaming_kernels(dt, shape):
     N, Cc, H, W = shape
     gen = torch.Generator().manual_seed(N * 100 + Cc)
     v = 4 if dt == torch.float32 else 8
-    tol = 1e-4 if dt == torch.float32 else 2e-2
     x = torch.randn(N, Cc, H, W, generator=gen)
     w = torch.randn(1, Cc, 3, 3, generator=gen) * (1.0 / (9 * Cc) ** 0.5)
     if dt == torch.bfloat16:
@@ -255,18 +280,23 @@ def test_conv3x3_c1_streaming_kernels(dt, shape):
     with pytest.raises(BtsAmdError):         # the kernels index w by x's (padded) channel count: a narrower weight must not reach them
         ops.conv3x3_c1_fwd(xd, wd[:, :Cc - 1].contiguous(), 80.0, scd)
     y = ops.conv3x3_c1_fwd(xd, wd, 80.0, scd)
-    assert rel(y.unsqueeze(1), yr) < (1e-5 if dt == torch.float32 else 5e-3)
+    assert rel(y.unsqueeze(1), yr) < (1e-5 if dt == torch.float32 else 1e-4)     # f32 output on both paths, identical bf16 operands
     gyd = gy.squeeze(1).to(DEV).contiguous()
     gx = torch.full(xd.shape, float("nan"), dtype=dt, device=DEV)
     ops.conv3x3_c1_dgrad(gyd, y, wd, gx, False, 80.0, scd)
-    assert rel(gx.float().permute(0, 3, 1, 2), xr.grad) < tol
+    bf = dt == torch.bfloat16
+    tol = BF16_ATOL if bf else 1e-4
+
+    def err(a, b, half_ulps=2.0):
+        return bf16_excess(a, b, half_ulps) if bf else rel(a, b)
+    assert err(gx.float().permute(0, 3, 1, 2), xr.grad) < tol
     base = _nhwc(torch.randn(x.shape, generator=gen), dt, v)
     yelu = _nhwc(torch.randn(x.shape, generator=gen), dt, v)
     fac = torch.where(yelu.float() > 0, torch.ones_like(yelu, dtype=torch.float32), yelu.float() + 1.0).permute(0, 3, 1, 2).cpu()
     ga = base.clone()
     ops.conv3x3_c1_dgrad(gyd, y, wd, ga, True, 80.0, scd, yelu)
     want = (xr.grad + base.float().permute(0, 3, 1, 2).cpu()) * fac
-    assert rel(ga.float().permute(0, 3, 1, 2), want) < 2 * tol
+    assert err(ga.float().permute(0, 3, 1, 2), want) < 2 * tol
     gf = torch.empty_like(xd)
     ops.conv3x3_c1_dgrad(gyd, y, wd, gf, False, 80.0, None, yelu)       # no per-image scale: y was produced with one, so only shape-check
     assert torch.isfinite(gf.float()).all()
@@ -277,7 +307,7 @@ def test_conv3x3_c1_streaming_kernels(dt, shape):
     dwp = torch.full((1, 9, ktot), 0.5, device=DEV)
     ops.conv3x3_c1_wgrad(gyd, y, xd, dwp, 80.0, scd)
     got = (dwp[0, :, :Cc] - 0.5).t().reshape(Cc, 3, 3).cpu()            # [t][c] -> [c][ky][kx]
-    assert rel(got, wq_r.grad[0]) < (2e-4 if dt == torch.float32 else 5e-3)
+    assert rel(got, wq_r.grad[0]) < 2e-4                                  # f32 sums on both paths
     assert (dwp[0, :, Cc:] == 0.5).all()                                # the padding columns are not touched
 
 
@@ -317,8 +347,8 @@ def test_conv_dual_data_gradient(shape, mode):
         fac = torch.where(fold.float() > 0, torch.ones_like(fold, dtype=torch.float32), fold.float() + 1.0).permute(0, 3, 1, 2).cpu()
         want0 = (want0 + base0.float().permute(0, 3, 1, 2).cpu()) * fac
         want1 = want1 + base1.float().permute(0, 3, 1, 2).cpu()[:, :4]
-    assert rel(g0.float().permute(0, 3, 1, 2), want0) < 2e-2
-    assert rel(g1.float().permute(0, 3, 1, 2)[:, :4], want1) < 2e-2
+    assert bf16_excess(g0.float().permute(0, 3, 1, 2), want0) < BF16_ATOL
+    assert bf16_excess(g1.float().permute(0, 3, 1, 2)[:, :4], want1) < BF16_ATOL
     assert g1[..., 4:].float().abs().max().item() == (base1[..., 4:].float().abs().max().item() if acc else 0.0)
 
 
@@ -353,7 +383,7 @@ def test_conv_wgrad_group():
     ConvLayer.wgrad_group(items)
     for (L, segs, dzd, dwp), ref, one in zip(items, refs, singles):
         assert rel(dwp, one) < 1e-5, L.name
-        assert rel(L.unpack_wgrad(dwp, dt).cpu(), ref) < 2e-2, L.name
+        assert rel(L.unpack_wgrad(dwp, dt).cpu(), ref) < 1e-4, L.name        # f32 sums from identical bf16-rounded operands
     # fewer than five, and a second call accumulates on top
     ConvLayer.wgrad_group(items[:2])
     for (L, segs, dzd, dwp), one in zip(items[:2], singles[:2]):
@@ -395,9 +425,9 @@ def test_batchnorm_train_fwd_bwd(dt, relu, shape):
     gen = torch.Generator().manual_seed(7)
     N, C, H, W = shape
     v = 4 if dt == torch.float32 else 8
-    tol = 1e-4 if dt == torch.float32 else 2e-2
+    bf = dt == torch.bfloat16
     x = torch.randn(N, C, H, W, generator=gen) * 1.5 + 0.3
-    if dt == torch.bfloat16:
+    if bf:
         x = x.to(dt).float()
     g = torch.rand(C, generator=gen) + 0.5
     b = torch.rand(C, generator=gen) - 0.5
@@ -408,19 +438,29 @@ def test_batchnorm_train_fwd_bwd(dt, relu, shape):
     if relu:
         y = F.relu(y)
     gy = torch.randn(y.shape, generator=gen)
+    if bf:
+        gy = gy.to(dt).float()          # identical operands on both sides: what differs is the ONE rounding of each stored result
     y.backward(gy)
+
+    def close(a_, b_, what):
+        """f32: 1e-4 max-norm (5e-4 for the gradients: two reductions deep); bf16-stored: element-wise 2^-8 |b| + 1e-4 max|b|, with
+        <= 3 elements per tensor allowed on the other side of a ReLU mask"""
+        if not bf:
+            assert rel(a_, b_) < (1e-4 if what == "y" else 5e-4), what
+        else:
+            assert bf16_bad(a_, b_) <= (3 if relu else 0), (what, bf16_bad(a_, b_), bf16_excess(a_, b_))
 
     xt = _nhwc(x, dt, v)
     mean, var = ops.bn_stats(xt)
     rm_d, rv_d = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     invstd, scale, shift = ops.bn_prepare(mean, var, N * H * W, g.to(DEV), b.to(DEV), 1.1e-5, 0.01, rm_d, rv_d)
     yt = ops.affine_act(xt, scale, shift, ACT_RELU if relu else ACT_NONE)
-    assert rel(yt.float().permute(0, 3, 1, 2), y) < tol
+    close(yt.float().permute(0, 3, 1, 2), y, "y")
     assert rel(rm_d, rm) < 1e-4 and rel(rv_d, rv) < 1e-4
     dx = torch.empty_like(xt)
     db, dg = ops.bn_bwd(_nhwc(gy, dt, v), xt, mean, invstd, g.to(DEV), b.to(DEV), relu, dx, False)
-    assert rel(dx.float().permute(0, 3, 1, 2), xr.grad) < tol * 5
-    assert rel(dg, gr.grad) < tol * 5 and rel(db, br.grad) < tol * 5
+    close(dx.float().permute(0, 3, 1, 2), xr.grad, "dx")
+    assert rel(dg, gr.grad) < 5e-4 and rel(db, br.grad) < 5e-4          # f32 sums on both paths
     # accumulate form (a tensor that feeds several BatchNorms of the dense ASPP): dx += ..., bit-identical sums
     base = torch.randn(dx.shape, generator=gen).to(dt).to(DEV)
     acc = base.clone()
@@ -468,9 +508,14 @@ def test_batchnorm_concat_multi_segment(dt, case, train):
     if relu:
         y = F.relu(y)
     gy = torch.randn(y.shape, generator=gen)
+    bf = dt == torch.bfloat16
+    if bf:
+        gy = gy.to(dt).float()          # identical operands on both sides
     obj = (y * gy).sum()
     if copy:
         gy2 = torch.randn(y.shape, generator=gen)
+        if bf:
+            gy2 = gy2.to(dt).float()
         obj = obj + (F.relu(y) * gy2).sum()
     obj.backward()
     # ---- product
@@ -486,7 +531,10 @@ def test_batchnorm_concat_multi_segment(dt, case, train):
     out = torch.empty(N, H, W, ctot, dtype=dt, device=DEV)
     out2 = torch.empty_like(out) if copy else None
     ops.bn_apply(xt, stats, gd, bd, eps, relu, out, out2, 0.01 if train else 0.0, rmd if train else None, rvd if train else None)
-    assert rel(out.float().permute(0, 3, 1, 2), y) < tol
+    if bf:      # stored once: element-wise 2^-8 |y| + 1e-4 max|y|
+        assert bf16_bad(out.float().permute(0, 3, 1, 2), y) <= (3 if relu else 0), bf16_excess(out.float().permute(0, 3, 1, 2), y)
+    else:
+        assert rel(out.float().permute(0, 3, 1, 2), y) < tol
     if copy:
         assert torch.equal(out2, torch.relu(out))
     assert rel(rmd, rm_ref) < 1e-4 and rel(rvd, rv_ref) < 1e-4
@@ -499,10 +547,18 @@ def test_batchnorm_concat_multi_segment(dt, case, train):
     db, dg = ops.bn_bwd_ms(dy, xt, dxs, accs, stats, gd, bd, eps, relu, train, fold)
     c0 = 0
     for i, (z, dx, a, bs) in enumerate(zip(zr, dxs, accs, bases)):
-        got = dx.float() - bs.float() if a else dx.float()
-        assert rel(got.permute(0, 3, 1, 2), z.grad) < tol * (10 if a else 5), (case, i)
+        if not bf:
+            got = dx.float() - bs.float() if a else dx.float()
+            assert rel(got.permute(0, 3, 1, 2), z.grad) < tol * (10 if a else 5), (case, i)
+        elif fold or copy:
+            # the ELU factor comes from the STORED (bf16) ELU output, x + 1 against autograd's exp(z): 2^-9 |x| apart; the ReLU-copy
+            # gradient is summed into dy in bf16 first (a second rounding of the incoming gradient): bounded, not rounding-exact
+            assert rel(dx.float().permute(0, 3, 1, 2), z.grad) < 1e-2, (case, i)
+        else:
+            want = z.grad + (bs.float().permute(0, 3, 1, 2).cpu() if a else 0.0)      # the stored value: (old +) gradient, rounded once
+            assert bf16_bad(dx.float().permute(0, 3, 1, 2), want) <= (3 if relu else 0), (case, i, bf16_excess(dx.float().permute(0, 3, 1, 2), want))
         c0 += z.shape[1]
-    assert rel(dg, gr.grad) < tol * 5 and rel(db, br.grad) < tol * 5
+    assert rel(dg, gr.grad) < (5e-4 if not (bf and (fold or copy)) else 1e-2) and rel(db, br.grad) < (5e-4 if not (bf and copy) else 1e-2)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
@@ -581,77 +637,127 @@ def test_layout_roundtrip_and_pack_maps():
         assert torch.equal(gm[s], g[..., s])
 
 
+def _plog(tag, **vals):
+    """measured parity figures -> gpurun_out/parity_bounds.jsonl (so that one GPU run shows how far inside its bound every check is)"""
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_bounds.jsonl"), "a") as f:
+            f.write(json.dumps(dict(tag=tag, **{k: (float("%.3e" % v) if isinstance(v, float) else v) for k, v in vals.items()})) + "\n")
+    except OSError:
+        pass
+
+
+def _chain_reference(x, ws, k, md, gy, base, fold, rounding):
+    """The reduction chain + head + LPG and its backward on the CPU.  rounding = True restates the bf16 kernel's ROUNDING POINTS
+    (csrc/lpg_chain.hip): every ELU output, every dz and the stored dx are rounded to bf16 once, the ELU derivative is taken from the
+    rounded ELU output (y > 0 ? 1 : y + 1), contractions accumulate in f32 (here f64, rounded to f32), the head runs in f32 on the
+    un-rounded accumulator of the last layer -- so kernel and reference differ only by f32 accumulation order and by the rare bf16
+    rounding decisions that order flips.  rounding = False is plain f32 autograd of the same chain (what the f32 kernel matches).
+    x: [cells, c0] (bf16-representable), ws: [co, ci] (bf16-representable when rounding), gy like the head output.
+    Returns (head output, dx [cells, c0], [dW_l])."""
+    bf = (lambda t: t.bfloat16().float()) if rounding else (lambda t: t)
+    mm = lambda a_, b_: (a_.double() @ b_.double()).float()
+    elu = (lambda z: torch.maximum(z, torch.exp(z.clamp(max=0.0)) - 1.0)) if rounding else F.elu
+    acts = [x.float()]
+    zs = []
+    for w in ws[:-1]:
+        zs.append(mm(acts[-1], w.t()))
+        acts.append(bf(elu(zs[-1])))
+    raw = mm(acts[-1], ws[-1].t()).requires_grad_(True)                     # [cells, 3 or 1]
+    B, h, w_ = gy.shape[0], (gy.shape[1] // k if k > 1 else gy.shape[1]), (gy.shape[2] // k if k > 1 else gy.shape[2])
+    r4 = raw.t().reshape(1, raw.shape[1], B * h, w_).reshape(raw.shape[1], B, h, w_).permute(1, 0, 2, 3)
+    out = (O.lpg(O.normalize_plane(O.plane_from_raw(r4, md)), k) / md) if k > 1 else torch.sigmoid(r4[:, 0])
+    out.backward(gy)
+    dz = bf(raw.grad)
+    dws = [None] * len(ws)
+    dA = None
+    for l in range(len(ws) - 1, -1, -1):
+        dws[l] = mm(dz.t(), acts[l])
+        dA = mm(dz, ws[l])
+        if l > 0:
+            y = acts[l]
+            dfac = torch.where(y > 0, torch.ones_like(y), y + 1.0) if rounding else torch.where(zs[l - 1] > 0, torch.ones_like(y), torch.exp(zs[l - 1]))
+            dz = bf(dA * dfac)
+    dx = dA + (base if base is not None else 0.0)
+    if fold:
+        xf = x.float()
+        dx = dx * torch.where(xf > 0, torch.ones_like(xf), xf + 1.0)
+    return out.detach(), bf(dx), dws
+
+
 @pytest.mark.parametrize("c0,k", [(64, 2), (32, 1), (16, 2), (64, 4), (16, 1), (32, 4), (64, 8), (16, 8), (128, 4), (128, 8)])
 @pytest.mark.parametrize("acc", [False, True])
-def test_lpg_chain_bwd_vs_autograd(c0, k, acc):
-    """Fused recompute backward of a narrow reduction chain + head (csrc/lpg_chain.hip) against PyTorch autograd of
-    the same chain written with torch ops on the bf16-rounded inputs (f32 math; the kernel rounds the intermediate
-    activations and gradients to bf16, hence the 3e-2 max-norm bar).  Cell count is not a multiple of the 32-cell tile."""
-    import torch.nn.functional as F
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_lpg_chain_bwd_vs_autograd(c0, k, acc, dt):
+    """Fused recompute backward of a reduction chain + head (csrc/lpg_chain.hip; bts.py:83-146 under autograd).
+    f32: against plain f32 autograd of the chain, 1e-4 (north_star's bound).
+    bf16: against a reference that restates the kernel's rounding points (_chain_reference): what is left is accumulation order, so
+    the bounds are those of a few flipped bf16 roundings (1e-3 class), not of five layers of bf16 noise (the 0.10 / 0.25 this test
+    carried before could not see a wrong tap or row).  Cell count is not a multiple of the 32-cell tile."""
     from bts_amd import chain
+    bf = dt == torch.bfloat16
+    if not chain.bwd_supported(c0, False, k, dt):
+        pytest.skip("no fused backward for this (c0, k, dtype)")
     gen = torch.Generator().manual_seed(7 * c0 + k)
     B, h, w, md = 2, 13, 21, 80.0
     dims = [c0]
     while dims[-1] > 8:
         dims.append(dims[-1] // 2)
     dims.append(3 if k > 1 else 1)
-    # (the 128-wide chains get xavier-scaled weights: with He scaling five layers drive the synthetic planes near-singular and
-    # the comparison measures their conditioning -- 6e-2 L2 on the k = 8 forward -- not the kernel)
-    gain = 1.0 if c0 >= 128 else 2.0
-    ws = [(torch.randn(dims[i + 1], dims[i], 1, 1, generator=gen) * (gain / dims[i]) ** 0.5).bfloat16().float() for i in range(len(dims) - 1)]
-    x = torch.randn(B, h, w, c0, generator=gen).bfloat16()
-    xr = x.float().permute(0, 3, 1, 2).clone().requires_grad_(True)
-    wr = [wi.clone().requires_grad_(True) for wi in ws]
-    a = xr
-    for i, wi in enumerate(wr):
-        a = F.conv2d(a, wi)
-        if i < len(wr) - 1:
-            a = F.elu(a)
-    ref = O.lpg(O.normalize_plane(O.plane_from_raw(a, md)), k) / md if k > 1 else torch.sigmoid(a)
-    gy = torch.randn(ref.shape, generator=gen)
-    ref.backward(gy)
-    wd = [wi.to(DEV) for wi in ws]
-    frags, frags_t = chain.pack_chain(wd, torch.bfloat16), chain.pack_chain_t(wd, torch.bfloat16)
-    xd = x.to(DEV)
-    out = chain.chain_fwd(xd, frags, c0, False, k, md)
-    wide = c0 >= 128            # one more bf16-rounded layer with a 128-wide contraction: ~1.5x the rounding noise
-    e_fwd = rel(out, ref.reshape(out.shape))
-    e_fwd2 = ((out.double().cpu() - ref.reshape(out.shape).detach().double()).norm() / ref.detach().double().norm()).item()
-    print("chain c0=%d k=%d fwd max-rel %.3e L2 %.3e" % (c0, k, e_fwd, e_fwd2))
-    # wide chains: the max norm is set by a few near-singular planes of this synthetic chain (k = 8: 0.20 max-rel on r02k while
-    # the same kernel inside the decoder gives lpg8x8 2.5e-3 L2 / 8.7e-3 max against the f32 oracle): bound the L2 norm there
-    assert (e_fwd2 < 5e-2 and e_fwd < 0.5) if wide else e_fwd < 2e-2
-    gx0 = torch.randn(B, h, w, c0, generator=gen).bfloat16()
-    gx = gx0.to(DEV) if acc else torch.full((B, h, w, c0), float("nan"), dtype=torch.bfloat16, device=DEV)
-    gws = [torch.zeros(dims[i + 1], max(dims[i], 8), device=DEV) for i in range(len(dims) - 1)]
-    chain.chain_bwd(xd, frags, frags_t, c0, k, md, gy.reshape(out.shape).to(DEV).contiguous(), gx, acc, gws)
+    gain = 1.0 if c0 >= 128 else 2.0       # (He-scaled 128-wide chains drive the synthetic planes near-singular)
+    rnd = (lambda t: t.bfloat16().float()) if bf else (lambda t: t)
+    ws = [rnd(torch.randn(dims[i + 1], dims[i], 1, 1, generator=gen) * (gain / dims[i]) ** 0.5) for i in range(len(dims) - 1)]
+    x = rnd(torch.randn(B, h, w, c0, generator=gen))
+    gy = torch.randn((B, h * k, w * k) if k > 1 else (B, h, w), generator=gen)
+    gx0 = rnd(torch.randn(B, h, w, c0, generator=gen))
+    w2 = [wi.reshape(wi.shape[0], wi.shape[1]) for wi in ws]
+    ref_out, ref_dx, ref_dw = _chain_reference(x.reshape(-1, c0), w2, k, md, gy, gx0.reshape(-1, c0) if acc else None, False, bf)
+    _, ref_dx_fold, _ = _chain_reference(x.reshape(-1, c0), w2, k, md, gy, gx0.reshape(-1, c0) if acc else None, True, bf)
+
     def rel_l2(a_, b_):
         a_, b_ = a_.detach().double().cpu(), b_.detach().double().cpu()
         return ((a_ - b_).norm() / b_.norm()).item()
-    want = xr.grad.permute(0, 2, 3, 1) + (gx0.float() if acc else 0.0)
-    # bf16 rounding of dz / activations at every layer: ~1 % per element, a few % on the ill-conditioned planes
-    # wide: five bf16-rounded layers on random N(0, 2/fan_in) weights (measured 1.9-3.4e-2 L2, gpurun r02i); at the benchmarked
-    # configuration, with xavier weights, the same kernels agree with the f32 oracle to 4-5e-3 (test_decoder_parity_at_bench_config)
-    # (the error of this synthetic chain grows ~1.4x per layer towards the ill-conditioned plane head: 1.9e-2, 2.3e-2, 3.4e-2,
-    # 5.1e-2 ... for the five layers of the 128-wide chain; a wrong tile or fragment order is an O(1) error)
-    l2b, mxb, mxw = (0.10, 0.25, 0.20) if wide else (2e-2, 8e-2, 5e-2)
-    print("chain c0=%d k=%d dx L2 %.3e max %.3e" % (c0, k, rel_l2(gx.float(), want), rel(gx.float(), want)))
-    assert rel_l2(gx.float(), want) < l2b and rel(gx.float(), want) < mxb
-    for g, wi in zip(gws, wr):
-        ref_g = wi.grad.reshape(wi.shape[0], wi.shape[1])
-        print("   dW %s L2 %.3e max %.3e" % (tuple(wi.shape[:2]), rel_l2(g[:, :wi.shape[1]], ref_g), rel(g[:, :wi.shape[1]], ref_g)))
-        assert rel_l2(g[:, :wi.shape[1]], ref_g) < l2b and rel(g[:, :wi.shape[1]], ref_g) < mxw
-        assert g[:, wi.shape[1]:].abs().max().item() == 0.0 if g.shape[1] > wi.shape[1] else True
+    wd = [wi.to(DEV) for wi in ws]
+    frags, frags_t = chain.pack_chain(wd, dt), chain.pack_chain_t(wd, dt)
+    xd = x.to(dt).to(DEV)
+    out = chain.chain_fwd(xd, frags, c0, False, k, md)
+    e_fwd, e_fwd2 = rel(out, ref_out.reshape(out.shape)), rel_l2(out, ref_out.reshape(out.shape))
+    _plog("chain_fwd", c0=c0, k=k, dt=str(dt), max=e_fwd, l2=e_fwd2)
+    # f32: 1e-4; bf16 vs the rounding-exact reference: the plane head amplifies the few flipped roundings (division by n1 u + n2 v + n3)
+    assert (e_fwd2 < 1e-5 and e_fwd < 1e-4) if not bf else (e_fwd2 < 5e-3 and e_fwd < 5e-2), (e_fwd, e_fwd2)
+    gx = gx0.to(dt).to(DEV) if acc else torch.full((B, h, w, c0), float("nan"), dtype=dt, device=DEV)
+    gws = [torch.zeros(dims[i + 1], max(dims[i], 8), device=DEV) for i in range(len(dims) - 1)]
+    gyd = gy.to(DEV).contiguous()
+    chain.chain_bwd(xd, frags, frags_t, c0, k, md, gyd, gx, acc, gws)
+    want = ref_dx.reshape(B, h, w, c0)
+    e_l2, e_mx = rel_l2(gx.float(), want), rel(gx.float(), want)
+    bad = bf16_bad(gx.float(), want, 2.0, 2e-3) if bf else 0
+    _plog("chain_bwd_dx", c0=c0, k=k, acc=acc, dt=str(dt), l2=e_l2, max=e_mx, bad=bad, n=gx.numel())
+    if bf:      # element-wise: 2^-8 |b| + 2e-3 max|b| for all but 0.2 % of the elements (a flipped rounding upstream moves a whole cell)
+        assert e_l2 < 5e-3 and bad <= 2e-3 * gx.numel(), (e_l2, e_mx, bad)
+    else:
+        assert e_mx < 1e-4 and e_l2 < 1e-5, (e_l2, e_mx)
+    for li, (g, rg) in enumerate(zip(gws, ref_dw)):
+        ci = rg.shape[1]
+        l2, mxv = rel_l2(g[:, :ci], rg), rel(g[:, :ci], rg)
+        _plog("chain_bwd_dw", c0=c0, k=k, acc=acc, dt=str(dt), layer=li, l2=l2, max=mxv)
+        assert (l2 < 2e-3 and mxv < 5e-3) if bf else (l2 < 1e-5 and mxv < 1e-4), (li, l2, mxv)
+        assert g[:, ci:].abs().max().item() == 0.0 if g.shape[1] > ci else True
     # x_is_elu_output: the chain completes the gradient of its input, an ELU output, and takes it through the ELU:
-    # (dx [+ old]) * (x > 0 ? 1 : x + 1) -- bit-identical to applying the factor to the plain result (same rounding points:
-    # the sum is rounded to bf16 once, after the multiplication, so compare against the f32 formula within bf16 rounding)
-    gx2 = gx0.to(DEV) if acc else torch.full((B, h, w, c0), float("nan"), dtype=torch.bfloat16, device=DEV)
+    # (dx [+ old]) * (x > 0 ? 1 : x + 1), rounded once
+    gx2 = gx0.to(dt).to(DEV) if acc else torch.full((B, h, w, c0), float("nan"), dtype=dt, device=DEV)
     gws2 = [torch.zeros_like(g) for g in gws]
-    chain.chain_bwd(xd, frags, frags_t, c0, k, md, gy.reshape(out.shape).to(DEV).contiguous(), gx2, acc, gws2, True)
-    fac = torch.where(x.float() > 0, torch.ones(x.shape), x.float() + 1.0)
-    assert rel_l2(gx2.float(), want * fac) < l2b and rel(gx2.float(), want * fac) < mxb
-    plain = gx.float().cpu() * fac                   # the unfolded kernel result (already bf16-rounded) times the factor
-    assert rel_l2(gx2.float(), plain) < 1e-2
+    chain.chain_bwd(xd, frags, frags_t, c0, k, md, gyd, gx2, acc, gws2, True)
+    wantf = ref_dx_fold.reshape(B, h, w, c0)
+    if bf:
+        assert rel_l2(gx2.float(), wantf) < 5e-3 and bf16_bad(gx2.float(), wantf, 2.0, 2e-3) <= 2e-3 * gx.numel()
+    else:
+        assert rel(gx2.float(), wantf) < 1e-4
+    for g, g2 in zip(gws, gws2):
+        assert rel(g2, g) < 1e-5          # same sums, atomics in a different order
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

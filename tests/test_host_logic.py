@@ -1,5 +1,8 @@
 """Host-side logic of the HIP path that can be checked without a GPU: weight-fragment packing indices, the block
 ranges of the batched pack / unpack launches, the decoder plan, and the profiler's kernel labels."""
+import os
+import sys
+
 import pytest
 import torch
 
@@ -201,3 +204,32 @@ def test_deferred_weight_gradients_group_in_arrival_order(monkeypatch):
     for n in names[:5]:
         run._wgrad(FakeLayer(n, True), [FakeT()], FakeT(), None)
     assert log == [("single", n) for n in names[:5]], log                      # the group of five fell back, layer by layer
+
+
+def test_bench_gpus_n_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher around it must start two ranks itself (the reference spawns its own:
+    bts_main.py:600-602) and report the world it ran in; under a launcher whose world differs from --gpus it must refuse."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--plumbing-only", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["sum_ranks"] == 3.0 and abs(j["max_elapsed"] - 0.002) < 1e-12
+    # a launcher world that disagrees with --gpus: refuse rather than print a line with the wrong n_gpus
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--plumbing-only", "1"],
+                         capture_output=True, text=True, timeout=120, env=env2)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
+def test_build_manifest_matches_sources():
+    """build() reuses binaries by content, not mtime: after a build the manifest must describe the current sources and library."""
+    from bts_amd import build as b
+    if not os.path.exists(b.LIB):
+        pytest.skip("library not built")
+    assert b.verify_library()
