@@ -396,11 +396,58 @@ def lpg_op_roofline(B, H, W, replays=5):
             del graph
         del eqs, gs, outs, geqs
     torch.cuda.empty_cache()
-    ach = tot_b / tot_s / 1e9
-    return {"kernel": "lpg_fwd/bwd_kernel<k=8,4,2> (bare LPG operator, TF-op boundary)", "bound": "hbm", "achieved": round(ach, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-            "alg_bytes_per_launch": round(tot_b / 6), "shape": "%dx%dx%d" % (B, H, W), "hbm_resident": True,
-            "timing": "hipGraph replay of the buffer rotation (device time incl. inter-kernel gaps)", "per_kernel": res}
+    single = tot_b / tot_s / 1e9
+    # The same six problems as TWO launches (bts_lpg_fwd_multi / bts_lpg_bwd_multi: the k = 8, 4, 2 heads of one batch handed over
+    # together): at this shape a single scale is 14-27 MB behind a ~2 us launch boundary, which alone caps three dependent launches
+    # near 0.45 of the HBM peak.  Same rotation discipline (> 256 MiB per buffer class), same graph-replay timing.
+    ks = (8, 4, 2)
+    per = sum(B * H * W * 4 * 2 + B * (H // k) * (W // k) * 16 * 2 for k in ks)
+    nrot = max(2, ((768 << 20) + per - 1) // per)
+    eqs = [[torch.randn(B, H // k, W // k, 4, device=dev) for k in ks] for _ in range(nrot)]
+    for r in eqs:
+        for e in r:
+            e[..., 2] += 3.0
+    gs = [[torch.randn(B, H, W, device=dev) for _ in ks] for _ in range(nrot)]
+    outs = [[torch.empty(B, H, W, device=dev) for _ in ks] for _ in range(nrot)]
+    geqs = [[torch.empty(B, H // k, W // k, 4, device=dev) for k in ks] for _ in range(nrot)]
+    mb, ms, mres = 0.0, 0.0, {}
+    for name, fn, byts in (("fwd", lambda i: ops.lpg_fwd_multi(eqs[i], list(ks), outs=outs[i]), sum(B * H * W * 4 * (1 + 4.0 / (k * k)) for k in ks)),
+                           ("bwd", lambda i: ops.lpg_bwd_multi(gs[i], eqs[i], list(ks), outs=geqs[i]), sum(B * H * W * 4 * (1 + 8.0 / (k * k)) for k in ks))):
+        for i in range(nrot):
+            fn(i)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for i in range(nrot):
+                    fn(i)
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(replays):
+            graph.replay()
+        e.record()
+        torch.cuda.synchronize()
+        sec = s.elapsed_time(e) * 1e-3 / (replays * nrot)
+        mres["k842_%s_GBps" % name] = round(byts / sec / 1e9, 1)
+        mres["k842_%s_us" % name] = round(sec * 1e6, 2)
+        mb += byts
+        ms += sec
+        del graph
+    del eqs, gs, outs, geqs
+    torch.cuda.empty_cache()
+    ach = mb / ms / 1e9
+    return {"kernel": "lpg_multi_kernel (bare LPG operator, k = 8, 4, 2 of one batch in one launch: bts_lpg_fwd_multi / bts_lpg_bwd_multi)",
+            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "alg_bytes_per_launch": round(mb / 2), "shape": "%dx%dx%d" % (B, H, W), "hbm_resident": True,
+            "timing": "hipGraph replay of the buffer rotation (device time incl. inter-kernel gaps)", "per_launch": mres,
+            "single_scale_launches": {"kernel": "lpg_fwd/bwd_kernel<k=8,4,2>: the same six problems as six launches (TF-op boundary as is)",
+                                      "achieved": round(single, 1), "frac": round(single / HBM_PEAK_GBS, 4),
+                                      "alg_bytes_per_launch": round(tot_b / 6), "per_kernel": res}}
 
 
 def infer_main(args):

@@ -48,6 +48,7 @@ class ConvDesc(C.Structure):
         ("out_scale", C.c_float), ("out_scale_n", C.c_void_p), ("accumulate", C.c_int32),
         ("fold_elu_y", C.c_void_p), ("fold_elu_stride", C.c_int32),
         ("w2", C.c_void_p), ("y2", C.c_void_p), ("Cout2", C.c_int32), ("y2_stride", C.c_int32), ("accumulate2", C.c_int32),
+        ("w_frag", C.c_int32),
     ]
 
 
@@ -55,7 +56,7 @@ class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("cmap", C.c_void_p),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("KK", C.c_int32), ("mode", C.c_int32),
                 ("R", C.c_int32), ("K", C.c_int32), ("T", C.c_int32),
-                ("tapmask", C.c_uint16 * MAX_TAP), ("first_block", C.c_int32)]
+                ("tapmask", C.c_uint16 * MAX_TAP), ("first_block", C.c_int32), ("layout", C.c_int32), ("Tp", C.c_int32)]
 
 
 class AugParams(C.Structure):
@@ -89,6 +90,8 @@ SIGNATURES = {
     "bts_current_device": [],
     "bts_lpg_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
     "bts_lpg_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "bts_lpg_fwd_multi": [_i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "bts_lpg_bwd_multi": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "bts_lpg_head_fwd": [_p, _i, _p, _p, _i, _i, _i, _i, _f, _p],
     "bts_lpg_head_bwd": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "bts_plane_fwd": [_p, _i, _p, _l, _f, _p],

@@ -126,6 +126,11 @@ def _wgrad_kernel(dtype, cout, radius1, up, n, hg, wg, cols=None):
     return "conv_wgrad<%s,%s>" % (_dn(dtype), "128x128" if cout > 64 else ("64x128k2" if cout > 32 else "32x128k4"))
 
 
+def _res_enabled():
+    """BTS_RES = 0 keeps every weight operand in the [rows][taps][K] layout, i.e. conv_igemm_res off (A/B switch; default on)."""
+    return os.environ.get("BTS_RES", "1") != "0"
+
+
 class ConvLayer:
     """Geometry + weight packing of one conv.  seg_channels: logical channels per input tensor."""
 
@@ -168,6 +173,53 @@ class ConvLayer:
             )
             self._cache[key] = tb
         return tb
+
+    # -- weight layout -------------------------------------------------------------------------
+    def frag_layout(self, dtype, rows, K, dgrad=False):
+        """bts_conv_desc_t::w_frag of the operand of a forward (rows = Cout, K = padded input channels) or data-gradient launch
+        (rows = padded channels of the input segment, K = padded Cout): 1 = MFMA A-fragment order for conv_igemm_res -- bf16, more
+        than 64 output rows, at most four 64-deep chunks of K (the kernel keeps the whole pixel operand of a tile resident), and a
+        launch that ALWAYS goes to the implicit GEMM whatever the map size: 1x1, dilated 3x3, sub-pixel up-convolutions.  In this
+        decoder: the data gradients of the five dense-ASPP 1x1 layers (K = 256), daspp_3's 1x1 forward, reduc8x8's 128 -> 128 layer.
+        Radius-1 3x3 layers are decided per geometry inside the library and keep the row-major operand.  Mirrors launch_fwd()
+        (csrc/conv_igemm.hip), which refuses a fragment operand it cannot use."""
+        if not (_res_enabled() and dtype == torch.bfloat16 and rows > 64 and (self.up or self.kk == 1 or self.dil > 1)):
+            return 0
+        nphase, Tp = self._launch_taps(dgrad)
+        if Tp > 1 and nphase == 1 and K % 64 == 0:        # launch_fwd() runs those channel-chunk-major; the fragment order is tap-major
+            return 0
+        return 1 if _cdiv(Tp * K, 64) <= 4 else 0
+
+    def frag_bytes(self, rows, K, dgrad):
+        """size of a fragment-order operand (zero-initialised by the caller; the pack kernel writes the real entries)"""
+        nphase, Tp = self._launch_taps(dgrad)
+        return nphase * 4 * _cdiv(rows, 128) * _cdiv(Tp * K, 64) * 4096
+
+    def _launch_taps(self, dgrad):
+        """(phases, taps per phase) of the LAUNCH that consumes the operand: the data gradient of an up-convolution runs its 16 taps
+        as one phase (input scale 2), everything else as the layer is described"""
+        return (1, self.nphase * self.T) if (dgrad and self.up) else (self.nphase, self.T)
+
+    @staticmethod
+    def to_frag(wp, nphase):
+        """Row-major packed operand [R][nphase*Tp][K] (bf16) -> fragment order, by plain torch indexing: the host-side statement of
+        the layout (tests hold the pack kernel's fragment stores against it)."""
+        R, Tt, K = wp.shape
+        Tp = Tt // nphase
+        RT = 4 * _cdiv(R, 128)
+        nch = _cdiv(Tp * K, 64)
+        dev = wp.device
+        wpad = torch.zeros((RT * 32, nphase, Tp * K + 64), dtype=wp.dtype, device=dev)
+        wpad[:R, :, :Tp * K] = wp.reshape(R, nphase, Tp * K)
+        c = torch.arange(nch, device=dev)[:, None, None, None]
+        sidx = torch.arange(4, device=dev)[None, :, None, None]
+        g = torch.arange(2, device=dev)[None, None, :, None]
+        e = torch.arange(8, device=dev)[None, None, None, :]
+        col = 64 * c + 16 * sidx + 8 * g + e
+        col = torch.where(col < Tp * K, col, torch.full_like(col, Tp * K)).expand(nch, 4, 2, 8)     # past the end: a zero column
+        src = wpad.reshape(RT, 32, nphase, Tp * K + 64).permute(2, 0, 1, 3)                # [ph][rt][row][col]
+        out = src[:, :, :, col]                                                            # [ph][rt][row][c][s][g][e]
+        return out.permute(0, 1, 3, 4, 5, 2, 6).contiguous().reshape(-1)                   # [ph][rt][c][s][lane = 32 g + row][e]
 
     # -- weight packing ------------------------------------------------------------------------
     def pack_fwd(self, weight, dtype):
@@ -212,9 +264,9 @@ class ConvLayer:
         d.Hx, d.Wx = segs[0].shape[1], segs[0].shape[2]
         return d
 
-    def forward(self, segs, wp, out, act, out_scale=1.0, out_scale_n=None):
+    def forward(self, segs, wp, out, act, out_scale=1.0, out_scale_n=None, w_frag=0):
         """segs: NHWC input tensors (padded channels); wp = pack_fwd(weight); out: NHWC [N,Ho,Wo,>=Cout]
-        or a single-channel f32 map [N,Ho,Wo]."""
+        or a single-channel f32 map [N,Ho,Wo].  w_frag: layout of wp (frag_layout())."""
         dtype = segs[0].dtype
         N, Hx, Wx, _ = segs[0].shape
         d = self._desc(dtype, segs, N, Hx, Wx)
@@ -223,6 +275,7 @@ class ConvLayer:
         for i, (dy, dx, a, b) in enumerate(self.taps):
             d.dy[i], d.dx[i], d.ioy[i], d.iox[i] = dy, dx, 0, 0
         d.w = wp.data_ptr()
+        d.w_frag = w_frag
         d.Cout = self.cout
         self._set_out(d, out)
         d.osc = 2 if self.up else 1
@@ -235,7 +288,7 @@ class ConvLayer:
             kv = sum(pad_to(c, vec_of(dtype)) for c in self.seg_channels) // vec_of(dtype)
             nb = (sum(t.shape[3] for t in segs) * M * segs[0].element_size() + out.numel() * out.element_size()
                   + wp.numel() * wp.element_size())            # inputs once + output once + packed weights
-            profiler.note(_fwd_kernel(dtype, self.cout, self.kk == 9 and self.dil == 1, (N, Hx, Wx), kv, self.up), "mfma",
+            profiler.note("conv_igemm_res<bf16,128xN>" if w_frag else _fwd_kernel(dtype, self.cout, self.kk == 9 and self.dil == 1, (N, Hx, Wx), kv, self.up), "mfma",
                           2.0 * M * self.nphase * self.T * self.cin * self.cout, self.name + ".fwd", nb)
         call("bts_conv_fwd", C.byref(d), stream_ptr())
         return out
@@ -249,7 +302,7 @@ class ConvLayer:
         else:
             d.y_stride, d.Hy, d.Wy = pix_stride(out), out.shape[1], out.shape[2]
 
-    def dgrad(self, dz, wd, seg_index, gx, accumulate, fold_elu_y=None):
+    def dgrad(self, dz, wd, seg_index, gx, accumulate, fold_elu_y=None, w_frag=0):
         """gx (+)= data-gradient w.r.t. input segment seg_index.  dz: NHWC [N,Ho,Wo,Cout_pad].
         fold_elu_y: that segment's forward tensor when it is an ELU output whose gradient this launch completes: the stored
         value is (gx [+ old]) * ELU'(fold_elu_y) (include/bts_amd.h: bts_conv_desc_t::fold_elu_y)."""
@@ -266,6 +319,7 @@ class ConvLayer:
             for i, (dy, dx, a, b) in enumerate(self.taps):
                 d.dy[i], d.dx[i], d.ioy[i], d.iox[i] = -dy, -dx, 0, 0
         d.w = wd.data_ptr()
+        d.w_frag = w_frag
         d.Cout = gx.shape[3]
         self._set_out(d, gx)
         d.osc = 1
@@ -279,7 +333,8 @@ class ConvLayer:
             d.fold_elu_y, d.fold_elu_stride = fold_elu_y.data_ptr(), pix_stride(fold_elu_y)
         if profiler.ACTIVE is not None:
             cseg = self.seg_channels[seg_index]
-            profiler.note(_fwd_kernel(dtype, gx.shape[3], self.kk == 9 and self.dil == 1 and not self.up, (N, Hg, Wg),
+            profiler.note("conv_igemm_res<bf16,128xN>" if w_frag else
+                          _fwd_kernel(dtype, gx.shape[3], self.kk == 9 and self.dil == 1 and not self.up, (N, Hg, Wg),
                                       pad_to(self.cout, vec_of(dtype)) // vec_of(dtype)), "mfma",
                           2.0 * N * Hg * Wg * len(self.taps) * cseg * self.cout, "%s.dgrad%d" % (self.name, seg_index),
                           dz.numel() * dz.element_size() + wd.numel() * wd.element_size()

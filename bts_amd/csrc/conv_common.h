@@ -60,6 +60,7 @@ struct ConvK {
     int n_col_tiles, nchunks, chunks_per_split;
     int halo_ok;   // every tap within radius 1 on an unscaled same-size input: eligible for conv_halo
     int kmajor;    // conv_igemm_dma K order: 1 = channel chunk outer, taps inner (needs KV % 8 == 0); 0 = tap outer
+    int wfrag;     // bts_conv_desc_t::w_frag: 0 = [Cout][taps][K] weights, 1 = MFMA A-fragment order (conv_igemm_res)
 };
 
 // The strength-reduced address paths multiply (pixel index) x (pixel stride in bytes) in 32 bits: a launcher that uses them

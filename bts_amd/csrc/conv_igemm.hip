@@ -310,6 +310,210 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_igemm_res: short-K launches with MANY output-channel tiles -- the data gradients of the dense-ASPP 1x1 layers (K = 256
+// channels of dz -> 576 .. 960 channels: 5 .. 8 tiles of 128) and daspp_3's 1x1 forward (round 5).
+//
+// On conv_igemm_dma such a launch is 2 000 - 3 300 tiles of FOUR chunks each: every tile pays the pipeline prologue, re-stages the
+// same 64 KiB of pixel rows its 4 - 7 sibling tiles stage, and ends in a read-modify-write epilogue -- the fit over the launch
+// table says 65 % of their time is per-tile fixed cost (tools/fit_fixed_cost.py), and they run at 390 - 420 TFLOP/s.  Here a
+// workgroup owns a PIXEL tile and walks all output-channel tiles:
+//   * the pixel operand (<= 4 chunks x 128 rows x 128 B = 64 KiB) is staged ONCE by LDS-DMA -- pipelined under the first
+//     output tile's MFMAs exactly like conv_igemm_dma's chunks -- and stays resident: from the second output tile on there is no
+//     DMA and no barrier in the loop;
+//   * the weights never touch LDS: they arrive in MFMA A-FRAGMENT ORDER (bts_conv_desc_t::w_frag: written by this library's pack
+//     kernel) and are loaded global -> VGPR, one fully coalesced 16-byte load per fragment (a wave instruction reads 1 KiB of
+//     consecutive bytes; the whole operand is <= 0.5 MiB and L2-resident).  A registers are single-buffered: the fragment of
+//     (next chunk, k-step s) is requested right behind the last MFMA that reads k-step s (MFMA sources are read at issue, the load
+//     returns hundreds of cycles later), retired by a COUNTED vmcnt in front of the k-step that needs it;
+//   * fragment reads run one k-step ahead straight across chunk boundaries (everything is resident);
+//   * one prologue per pixel tile; the epilogue of output tile t overlaps the loop of the CU's other workgroup.
+// The loads are inline asm on purpose: beside an LDS-DMA in flight hipcc waits vmcnt(0) at the first use of ANY ordinary load's
+// result (seen in the ISA of the first version: a full drain of the just-issued DMA in front of every chunk's first MFMA).
+// bf16 only, tap-major K order; pixel-side addressing, zero-page padding, XOR-swizzled LDS rows and the epilogues are conv_igemm_dma's.
+// ------------------------------------------------------------------------------------------------
+template <int OFF>
+__device__ __forceinline__ void gload16(u32x4_t& d, const char* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d) : "v"(p), "n"(OFF) : "memory");
+}
+
+constexpr int RES_MAX_CHUNKS = 4;
+
+template <int WR, int WC, int TM, int TN, int EPI>
+__global__ __launch_bounds__(64 * WR * WC) void conv_igemm_res(const ConvK a) {
+    using T = BF16;
+    constexpr int NW = WR * WC;
+    constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+    constexpr int RP = 8 * NW;
+    constexpr int RB = BN / RP;
+    constexpr int VEC = 8, ES = 2;
+    constexpr int BUF = BN * 128;
+    static_assert(BN % RP == 0 && RB >= 1 && RB <= 4, "tile rows must be a multiple of the DMA pass; <= 4 DMA issues per chunk (one per k-step)");
+    __shared__ __attribute__((aligned(16))) char smem[RES_MAX_CHUNKS * BUF + BTS_MAX_TAP * 8];
+    uint32_t* sTap = (uint32_t*)(smem + RES_MAX_CHUNKS * BUF);
+    int* sTapOff = (int*)(smem + RES_MAX_CHUNKS * BUF + BTS_MAX_TAP * 4);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int phase = blockIdx.y;
+    const int px_tile = remap_xcd(blockIdx.x, a.n_px_tiles);
+    if (tid < BTS_MAX_TAP) { sTap[tid] = a.taps[tid]; sTapOff[tid] = a.tapoff[tid]; }
+
+    const int pc = tid & 7, srow = tid >> 3;
+    const int vec = pc ^ ((srow >> 1) & 7);
+    int py[RB], px[RB];
+    uint32_t rowpix[RB], rowoff[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int m = px_tile * BN + srow + RP * i;
+        rowoff[i] = 0;
+        if (m < a.M) {
+            const uint32_t n = fdiv(m, a.fd_hw);
+            const uint32_t rem = m - n * (uint32_t)(a.Hg * a.Wg);
+            const uint32_t y = fdiv(rem, a.fd_w);
+            const uint32_t x = rem - y * a.Wg;
+            py[i] = (int)y;
+            px[i] = (int)x;
+            rowpix[i] = n * (uint32_t)(a.Hx * a.Wx) + (uint32_t)a.isc * (y * a.Wx + x);
+        } else {
+            py[i] = px[i] = -100000;
+            rowpix[i] = 0;
+        }
+    }
+    const int TKV = a.T * a.KV;
+    const int nchunks = (TKV + 7) >> 3;                                       // tap-major K order, <= RES_MAX_CHUNKS (launcher)
+    const char* zero = (const char*)kZeroPage;
+    __syncthreads();  // tap tables visible
+
+    // source addresses of one chunk's pixel rows: the full computation per chunk -- there are at most four of them per workgroup
+    const char* srcB[RB];
+    auto prep_chunk = [&](int chunk) {
+        const int kv = chunk * 8 + vec;
+        if (kv >= TKV) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) srcB[i] = zero;
+            return;
+        }
+        const int tap = kv / a.KV, cvk = kv - tap * a.KV;
+        int dy, dx, ioy, iox;
+        int seg, seg_end; const char* sp; uint32_t sb, coffB;
+        pick_seg_b(a, cvk, VEC * ES, seg, sp, sb, coffB, seg_end);
+        decode_tap(sTap[phase * a.T + tap], dy, dx, ioy, iox);
+        const int toff = sTapOff[phase * a.T + tap];
+        const char* base = sp + (long)coffB + (long)(toff * (int)sb);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const bool ok = (unsigned)(py[i] + dy) < (unsigned)a.Hg && (unsigned)(px[i] + dx) < (unsigned)a.Wg;
+            srcB[i] = ok ? base + rowpix[i] * sb : zero;
+        }
+    };
+
+    f32x16_t acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
+
+    const int wr = wave / WC, wc = wave % WC;
+    const int frow = lane & 31, fk = lane >> 5;
+    int offB[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) offB[j] = ((wc * TN + j) * 32 + frow) * 128;
+    const int swz = (frow >> 1) & 7;
+
+    // weight fragments: [phase][row tile][chunk][k-step][lane][16 B], row tiles padded to whole 128-row output tiles (zero rows):
+    // every output tile of the walk reads valid memory
+    const int RT = ((a.Cout + 127) >> 7) << 2;
+    const char* aptr[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) aptr[i] = a.w + ((size_t)(phase * RT + wr * TM + i) * nchunks) * 4096 + lane * 16;
+    const int next_tile_adv = ((BM / 32 - 1) * nchunks + 1) * 4096;          // from the last chunk of a tile to chunk 0 of the next
+    u32x4_t fa[TM][4];
+    auto ldA = [&](auto ic, auto sc) {
+        constexpr int i = decltype(ic)::value, s = decltype(sc)::value;
+        gload16<s * 1024>(fa[i][s], aptr[i]);
+    };
+    const uint32_t sBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+    u32x4_t fb[2][TN];
+    auto rd = [&](u32x4_t& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); };
+    auto rdB = [&](int set, int j, int c, int s) { rd(fb[set][j], sBase + c * BUF + offB[j] + (((2 * s + fk) ^ swz) << 4)); };
+    auto mm = [&](int s, int i, int j) {
+        __builtin_amdgcn_sched_barrier(0);
+        Mma<T>::run(fa[i][s], fb[s & 1][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // Output tile 0 stages the pixel chunks under its own MFMAs (chunk c+1 in flight during chunk c, one barrier per chunk, weight
+    // fragments retired by the chunk's vmcnt(0) together with the DMA); from tile 1 on everything on the pixel side is resident:
+    // no DMA, no barrier, counted vmcnt per k-step, fragment reads one k-step ahead across chunk boundaries.  ONE loop body and one
+    // epilogue site for both (wave-uniform branches): two inlined copies cost 24 more registers and a wave per SIMD.
+    prep_chunk(0);
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)srcB[i], (lptr_t)(smem + (wave * 8 + RP * i) * 128), 16, 0, 0);
+    static_for_n<TM>([&](auto ic) { static_for_n<4>([&](auto sc) { ldA(ic, sc); }); });
+    const int n_co = a.n_co_tiles;
+    for (int co = 0; co < n_co; ++co) {
+        const bool fill = co == 0;
+        for (int c = 0; c < nchunks; ++c) {
+            const bool stage = fill && c + 1 < nchunks;
+            if (stage) prep_chunk(c + 1);
+            const bool last = co + 1 == n_co && c + 1 == nchunks;             // nothing follows: the prefetch re-reads this chunk
+            const int adv = last ? 0 : (c + 1 < nchunks ? 4096 : next_tile_adv);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) aptr[i] += adv;
+            if (fill) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's rows of chunk c + its weight fragments;
+                __builtin_amdgcn_s_barrier();                                 // then everyone's rows
+            }
+            if (fill || c == 0) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) rdB(0, j, c, 0);
+            }
+            char* sBw = smem + (c + 1) * BUF;
+            auto dmaB = [&](int i) { if (stage) __builtin_amdgcn_global_load_lds((gptr_t)srcB[i], (lptr_t)(sBw + (wave * 8 + RP * i) * 128), 16, 0, 0); };
+            dmaB(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_setprio(1);
+            const bool ahead = !fill && c + 1 < nchunks;                      // next chunk's k-step 0 is read during this chunk's k-step 3
+            static_for_n<4>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                // resident tiles: fa[.][s] of this chunk was requested one chunk ago, TM requests per k-step: 3 k-steps' worth of
+                // younger requests may stay outstanding
+                // (chunk 0 of a resident tile waits for nothing: its fragments landed before the previous epilogue -- the vmcnt(0) in
+                // front of it -- and vmcnt retires in order, so ANY wait here would first drain that epilogue's stores; they get
+                // this chunk's 16 MFMAs to complete in the background)
+                if (!fill && c > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * TM) : "memory");
+                static_for_n<TM>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    static_for_n<TN>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        constexpr int slot = i * TN + j;
+                        constexpr int dma_slot = TN < TM * TN ? TN : 1;
+                        mm(s, i, j);
+                        if constexpr (slot < TN) {
+                            if constexpr (s < 3) rdB((s + 1) & 1, slot, c, s + 1);
+                            else { if (ahead) rdB(0, slot, c + 1, 0); }       // (fb set 0: its last reader was k-step 2)
+                        }
+                        if constexpr (slot == dma_slot && s + 1 < RB) dmaB(s + 1);
+                        if constexpr (j == TN - 1) ldA(ic, sc);
+                    });
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            });
+            __builtin_amdgcn_s_setprio(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the prefetch of the next tile's chunk 0 (or the final dummy): nothing may
+        __builtin_amdgcn_sched_barrier(0);                    // land in registers the epilogue reuses
+        conv_epilogue<T, WR, WC, TM, TN, EPI>(a, acc, co, px_tile, phase, wr, wc, frow, fk);
+        zero_acc();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side: which kernel takes a forward / data-gradient launch
 // ------------------------------------------------------------------------------------------------
 // The one run-time switch of this dispatch: BTS_CONV_WIDE = 0 | 1 | 2 -- conv_halo_wide off / where its fill heuristic says it pays
@@ -342,6 +546,35 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
         hipLaunchKernelGGL(kern, grid, dim3(threads), 0, st, k);
     };
     constexpr bool BF = T::kBytes == 2;
+    if (k.wfrag) {
+        // weights in A-fragment order: only conv_igemm_res reads that layout.  The caller decides by the static rule of
+        // bts_amd/conv.py::frag_layout (bf16, more than 64 output rows, a launch no 2-D-tile kernel takes, <= 4 chunks of K).
+        if constexpr (!BF) {
+            return BTS_ERR_ARG;
+        } else {
+            k.kmajor = 0;                                  // tap-major K order: the fragment layout's
+            const int nchunks = (k.T * k.KV + 7) >> 3;
+            if (k.Cout <= 64 || k.wfrag != 1 || nchunks > RES_MAX_CHUNKS) return BTS_ERR_ARG;
+            static const int layout = [] { const char* e = getenv("BTS_RES_LAYOUT"); return e ? atoi(e) : 0; }();
+            const int epi = epilogue_form(k, BF, true);
+            auto go_res = [&](auto kern, int bn) {
+                k.n_co_tiles = ceil_div(k.Cout, 128);
+                k.n_px_tiles = ceil_div(k.M, bn);
+                hipLaunchKernelGGL(kern, dim3(k.n_px_tiles, k.nphase), dim3(256), 0, st, k);
+            };
+#define BTS_RES_(E) do { if (layout == 1) go_res(conv_igemm_res<4, 1, 1, 4, E>, 128); else if (layout == 2) go_res(conv_igemm_res<2, 2, 2, 1, E>, 64); \
+                         else go_res(conv_igemm_res<2, 2, 2, 2, E>, 128); } while (0)
+            if (epi == 1) BTS_RES_(1);
+            else if (epi == 2) BTS_RES_(2);
+            else if (epi == 3) BTS_RES_(3);
+            else if (epi == 4) BTS_RES_(4);
+            else if (epi == 5) BTS_RES_(5);
+            else BTS_RES_(0);
+#undef BTS_RES_
+            BTS_LAUNCH_CHECK();
+            return BTS_OK;
+        }
+    }
     // 33..64 output channels over several channel chunks (conv2: 161 -> 64): the pipelined 64-co form of conv_halo_wide
     if (wide_mode() && BF && k.halo_ok && k.Cout > 32 && k.Cout <= 64 && k.nphase == 1 && k.T == 9 && k.KV > 8) {
         const int rc = launch_halo_wide(k, st, 0);
@@ -409,6 +642,8 @@ extern "C" int bts_conv_fwd(const bts_conv_desc_t* d, bts_stream_t stream) {
     BTS_CHECK_ARG(!(d->accumulate && d->act != BTS_ACT_NONE));
     BTS_CHECK_ARG(d->nphase == 1 || d->osc == 2);
     k.w = (const char*)d->w;
+    k.wfrag = d->w_frag;
+    BTS_CHECK_ARG(d->w_frag >= 0 && d->w_frag <= 1 && !(d->w_frag && d->y2));
     k.y = (char*)d->y;
     k.y_stride = d->y_stride;
     k.y_f32 = d->y_dtype == BTS_F32;

@@ -26,10 +26,10 @@ __device__ __forceinline__ float lpg_eval(float n1, float n2, float n3, float n4
 // ---- LPG op boundary: plane_eq [B][h][w][4] -> depth [B][hk][wk] ---------------------------
 // thread = (cell, group of RPT patch rows); lanes run over the cells of one coarse row
 template <int K, int RPT>
-__global__ __launch_bounds__(256) void lpg_fwd_kernel(const float* __restrict__ eq, float* __restrict__ depth,
-                                                      int cells, int h, int w, float div) {
+__device__ __forceinline__ void lpg_fwd_body(const float* __restrict__ eq, float* __restrict__ depth,
+                                             int cells, int h, int w, float div, long block) {
     constexpr int NR = K / RPT;
-    const long t = blockIdx.x * 256l + threadIdx.x;
+    const long t = block * 256l + threadIdx.x;
     if (t >= (long)cells * NR) return;
     const int j = (int)(t % w);
     const long q = t / w;
@@ -58,15 +58,20 @@ __global__ __launch_bounds__(256) void lpg_fwd_kernel(const float* __restrict__ 
     }
 }
 
+template <int K, int RPT>
+__global__ __launch_bounds__(256) void lpg_fwd_kernel(const float* __restrict__ eq, float* __restrict__ depth,
+                                                      int cells, int h, int w, float div) {
+    lpg_fwd_body<K, RPT>(eq, depth, cells, h, w, div, blockIdx.x);
+}
+
 // true gradient of out = n4 / (den * div).  Workgroup = (256 / NR) consecutive cells x NR row groups (thread = row group * CPB +
 // cell): each thread accumulates its RPT rows, the NR partials of a cell are summed through LDS in row order.
 template <int K, int RPT>
-__global__ __launch_bounds__(256) void lpg_bwd_kernel(const float* __restrict__ gdepth, const float* __restrict__ eq,
-                                                      float* __restrict__ geq, int cells, int h, int w, float div) {
+__device__ __forceinline__ void lpg_bwd_body(const float* __restrict__ gdepth, const float* __restrict__ eq,
+                                             float* __restrict__ geq, int cells, int h, int w, float div, long block, f32x4_t* part) {
     constexpr int NR = K / RPT, CPB = 256 / NR;
-    __shared__ f32x4_t part[NR > 1 ? 256 : 1];
     const int c = threadIdx.x % CPB, rg = threadIdx.x / CPB;
-    const long cell = (long)blockIdx.x * CPB + c;
+    const long cell = block * CPB + c;
     const bool on = cell < cells;
     float g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f;
     if (on) {
@@ -115,6 +120,52 @@ __global__ __launch_bounds__(256) void lpg_bwd_kernel(const float* __restrict__ 
             *(f32x4_t*)(geq + (size_t)cell * 4) = s;
         }
     }
+}
+template <int K, int RPT>
+__global__ __launch_bounds__(256) void lpg_bwd_kernel(const float* __restrict__ gdepth, const float* __restrict__ eq,
+                                                      float* __restrict__ geq, int cells, int h, int w, float div) {
+    __shared__ f32x4_t part[256];
+    lpg_bwd_body<K, RPT>(gdepth, eq, geq, cells, h, w, div, blockIdx.x, part);
+}
+
+// ---- several LPG problems in ONE launch (bts_lpg_fwd_multi / bts_lpg_bwd_multi) --------------------------------------------
+// At the training shape one scale moves 14-27 MB: 2.3-4 us of HBM time behind ~2 us of launch boundary, so three dependent launches
+// cannot pass ~0.45 of the HBM peak whatever the kernel does.  A caller that holds all plane equations (the TF-op boundary applied
+// to the three heads of one image batch: bts.py:227, 241, 255 share nothing but the stream) hands them over together: blocks are
+// dealt to the problems by range, each block runs the single-problem body of its (k, rows-per-thread) form.
+constexpr int LPG_MULTI_MAX = 4;
+struct LpgMulti {
+    const float* a[LPG_MULTI_MAX];      // fwd: plane_eq;   bwd: grad_depth
+    const float* b[LPG_MULTI_MAX];      // fwd: unused;     bwd: plane_eq
+    float* out[LPG_MULTI_MAX];          // fwd: depth;      bwd: grad_plane_eq
+    int cells[LPG_MULTI_MAX], h[LPG_MULTI_MAX], w[LPG_MULTI_MAX], k[LPG_MULTI_MAX], rpt[LPG_MULTI_MAX];
+    float div[LPG_MULTI_MAX];
+    int first[LPG_MULTI_MAX + 1];       // block ranges
+    int n;
+};
+template <bool BWD, int K, int RPT>
+__device__ __forceinline__ void lpg_multi_one(const LpgMulti& m, int p, long block, f32x4_t* part) {
+    if constexpr (BWD) lpg_bwd_body<K, RPT>(m.a[p], m.b[p], m.out[p], m.cells[p], m.h[p], m.w[p], m.div[p], block, part);
+    else lpg_fwd_body<K, RPT>(m.a[p], m.out[p], m.cells[p], m.h[p], m.w[p], m.div[p], block);
+}
+template <bool BWD>
+__global__ __launch_bounds__(256) void lpg_multi_kernel(const LpgMulti m) {
+    __shared__ f32x4_t part[BWD ? 256 : 1];
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < LPG_MULTI_MAX; ++i)
+        if (i < m.n && (int)blockIdx.x >= m.first[i]) p = i;
+    // per-field selects instead of a dynamic index into the by-value struct (that would go through scratch)
+    LpgMulti q;
+    q.n = 1;
+#define SEL(F) q.F[0] = p == 0 ? m.F[0] : (p == 1 ? m.F[1] : (p == 2 ? m.F[2] : m.F[3]))
+    SEL(a); SEL(b); SEL(out); SEL(cells); SEL(h); SEL(w); SEL(k); SEL(rpt); SEL(div); SEL(first);
+#undef SEL
+    const long block = (long)blockIdx.x - q.first[0];
+    const int k = q.k[0], rpt = q.rpt[0];
+#define FORM(KK, RR) if (k == KK && rpt == RR) { lpg_multi_one<BWD, KK, RR>(q, 0, block, part); return; }
+    FORM(8, 8) FORM(8, 4) FORM(8, 2) FORM(8, 1) FORM(4, 4) FORM(4, 2) FORM(4, 1) FORM(2, 2) FORM(2, 1)
+#undef FORM
 }
 
 // ---- fused head ------------------------------------------------------------------------------
@@ -459,6 +510,55 @@ extern "C" int bts_lpg_bwd(const float* grad_depth, const float* plane_eq, const
         case 4: return lpg_bwd_launch<4>(grad_depth, plane_eq, grad_plane_eq, cells, h, w, depth_div, st);
         default: return lpg_bwd_launch<2>(grad_depth, plane_eq, grad_plane_eq, cells, h, w, depth_div, st);
     }
+}
+
+static int lpg_multi_fill(LpgMulti& m, int n, const int* B, const int* h, const int* w, const int* k, const float* div, bool bwd) {
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        BTS_CHECK_ARG(B[i] > 0 && h[i] > 0 && w[i] > 0 && (k[i] == 2 || k[i] == 4 || k[i] == 8) && div[i] != 0.f);
+        BTS_CHECK_ARG((long)B[i] * h[i] * w[i] < (1l << 31));
+        const int cells = B[i] * h[i] * w[i];
+        const int rpt = k[i] == 8 ? lpg_rows_per_thread<8>(cells) : (k[i] == 4 ? lpg_rows_per_thread<4>(cells) : lpg_rows_per_thread<2>(cells));
+        m.cells[i] = cells; m.h[i] = h[i]; m.w[i] = w[i]; m.k[i] = k[i]; m.rpt[i] = rpt; m.div[i] = div[i];
+        m.first[i] = total;
+        const int nr = k[i] / rpt;
+        total += bwd ? ceil_div(cells, 256 / nr) : ceil_div((long)cells * nr, 256);
+    }
+    for (int i = n; i <= LPG_MULTI_MAX; ++i) m.first[i] = total;
+    m.n = n;
+    return total;
+}
+
+extern "C" int bts_lpg_fwd_multi(int n, const float* const* plane_eq, float* const* depth, const int* batch, const int* in_h,
+                                 const int* in_w, const int* upratio, const float* depth_div, bts_stream_t stream) {
+    BTS_CHECK_ARG(n >= 1 && n <= LPG_MULTI_MAX && plane_eq && depth && batch && in_h && in_w && upratio && depth_div);
+    LpgMulti m{};
+    for (int i = 0; i < n; ++i) {
+        BTS_CHECK_ARG(plane_eq[i] && depth[i] && ((uintptr_t)plane_eq[i] & 15) == 0 && ((uintptr_t)depth[i] & 15) == 0);
+        m.a[i] = plane_eq[i]; m.out[i] = depth[i];
+    }
+    const int total = lpg_multi_fill(m, n, batch, in_h, in_w, upratio, depth_div, false);
+    if (total < 0) return total;
+    hipLaunchKernelGGL(lpg_multi_kernel<false>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, m);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
+extern "C" int bts_lpg_bwd_multi(int n, const float* const* grad_depth, const float* const* plane_eq, float* const* grad_plane_eq,
+                                 const int* batch, const int* in_h, const int* in_w, const int* upratio, const float* depth_div,
+                                 bts_stream_t stream) {
+    BTS_CHECK_ARG(n >= 1 && n <= LPG_MULTI_MAX && grad_depth && plane_eq && grad_plane_eq && batch && in_h && in_w && upratio && depth_div);
+    LpgMulti m{};
+    for (int i = 0; i < n; ++i) {
+        BTS_CHECK_ARG(grad_depth[i] && plane_eq[i] && grad_plane_eq[i]);
+        BTS_CHECK_ARG(((uintptr_t)grad_depth[i] & 15) == 0 && ((uintptr_t)plane_eq[i] & 15) == 0 && ((uintptr_t)grad_plane_eq[i] & 15) == 0);
+        m.a[i] = grad_depth[i]; m.b[i] = plane_eq[i]; m.out[i] = grad_plane_eq[i];
+    }
+    const int total = lpg_multi_fill(m, n, batch, in_h, in_w, upratio, depth_div, true);
+    if (total < 0) return total;
+    hipLaunchKernelGGL(lpg_multi_kernel<true>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, m);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
 }
 
 extern "C" int bts_lpg_head_fwd(const float* raw, int raw_stride, float* depth, float* plane_eq, int B, int h, int w,

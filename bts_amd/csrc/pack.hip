@@ -97,16 +97,33 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const bts_pack_j
     // the index split below runs 36 times per thread: with KK a compile-time constant (3x3 and 1x1 are the only kernel
     // sizes of the decoder) the two divisions are multiply-shifts instead of ~40-instruction software divisions, which
     // made this kernel VALU-bound at under 1 TB/s
+    // (round 5) the gather is issued in batches of 12 independent loads per thread, all in flight before the first LDS store of the
+    // batch: written as one load / one store per iteration, hipcc waits for every 4-byte load before its store -- 36 dependent
+    // round trips per thread, which is what held this kernel at 1.3 TB/s.
     auto load_tile = [&](auto kkc) {
         const int kk = decltype(kkc)::value ? decltype(kkc)::value : KK;
         const int run = PACK_TILE * kk;
-        for (int i = tid; i < PACK_TILE * run; i += 256) {
-            const int co = i / run, rem = i - co * run;
-            const int e = rem / kk, sidx = rem - e * kk;
-            const int ci = ci_s[e];
-            float v = 0.f;
-            if (ci >= 0 && co0 + co < Cout) v = j.w[((size_t)(co0 + co) * Cin + ci) * kk + sidx];
-            tile[co * PACK_ROW + rem] = v;
+        constexpr int NB = 12;
+        for (int i0 = tid; i0 < PACK_TILE * run; i0 += 256 * NB) {
+            float v[NB];
+            int dst[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int i = i0 + 256 * b;
+                v[b] = 0.f;
+                dst[b] = -1;
+                if (i < PACK_TILE * run) {
+                    const int co = i / run, rem = i - co * run;
+                    const int e = rem / kk, sidx = rem - e * kk;
+                    const int ci = ci_s[e];
+                    dst[b] = co * PACK_ROW + rem;
+                    if (ci >= 0 && co0 + co < Cout) v[b] = __builtin_nontemporal_load(j.w + ((size_t)(co0 + co) * Cin + ci) * kk + sidx);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                if (dst[b] >= 0) tile[dst[b]] = v[b];
         }
     };
     if (KK == 9) load_tile(std::integral_constant<int, 9>{});
@@ -141,7 +158,17 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const bts_pack_j
                 for (int sidx = 0; sidx < 9; ++sidx) if (mask & (1u << sidx)) a += wv[x][sidx];
                 v[x] = a;
             }
-            *(u32x4_t*)((char*)j.out + (((size_t)r * Tn + t) * K + k) * T::kBytes) = T::pack(v);
+            if (j.layout == 0) {
+                *(u32x4_t*)((char*)j.out + (((size_t)r * Tn + t) * K + k) * T::kBytes) = T::pack(v);
+            } else {
+                // MFMA A-fragment order (bts_conv_desc_t::w_frag; bf16: this thread's 8 values are exactly one lane's 16 bytes);
+                // row tiles padded to whole 128-row output tiles
+                const int Tp = j.Tp, ph = t / Tp, tt = t - ph * Tp;
+                const int kk = tt * K + k, chunk = kk >> 6, kin = kk & 63, nch = (Tp * K + 63) >> 6;
+                const int RT = ((R + 127) >> 7) << 2;
+                const size_t vecidx = ((((size_t)ph * RT + (r >> 5)) * nch + chunk) * 4 + (kin >> 4)) * 64 + ((kin >> 3) & 1) * 32 + (r & 31);
+                *(u32x4_t*)((char*)j.out + vecidx * 16) = T::pack(v);
+            }
         }
     }
 }
@@ -214,6 +241,7 @@ extern "C" int bts_unpack_wgrad(const float* dwp, int Cout, int Cin, int KK, con
     return BTS_OK;
 }
 
+// (a job's `layout` != 0 is only meaningful for bf16: the host side never sets it for f32)
 extern "C" int bts_pack_weight_batch(const bts_pack_job_t* jobs, int n_jobs, long total_blocks, int dtype, bts_stream_t stream) {
     BTS_CHECK_ARG(jobs && n_jobs > 0 && total_blocks > 0 && total_blocks < (1l << 31) && (dtype == BTS_F32 || dtype == BTS_BF16));
     dim3 grid((unsigned)total_blocks);

@@ -118,6 +118,7 @@ class PackSet:
         dev = P[names[0] + ".weight"].device
         self.key = (dtype, tuple(P[n + ".weight"].data_ptr() for n in names))
         self.fwd, self.dgrad = {}, {}
+        self.fwd_frag, self.dgrad_frag = {}, {}       # bts_conv_desc_t::w_frag of each operand (ConvLayer.frag_layout)
         self.dwp_off, self.gw_off = {}, {}
         fjobs, djobs, ujobs = [], [], []
         dwp_total = gw_total = 0
@@ -126,13 +127,21 @@ class PackSet:
             w = P[n + ".weight"]
             tb = L.tables(dtype, dev)
             ttot = L.nphase * L.T
-            out = torch.empty((L.cout, ttot, tb["ktot"]), dtype=dtype, device=dev)
-            self.fwd[n] = out
-            fjobs.append(self._pjob(w, out, tb["cmap"], L, 0, L.cout, tb["ktot"], ttot))
+            lay = L.frag_layout(dtype, L.cout, tb["ktot"])
+            if lay:       # MFMA A-fragment order for conv_igemm_res: zeroed once, the pack kernel writes the real entries
+                out = torch.zeros(L.frag_bytes(L.cout, tb["ktot"], False) // 2, dtype=dtype, device=dev)
+            else:
+                out = torch.empty((L.cout, ttot, tb["ktot"]), dtype=dtype, device=dev)
+            self.fwd[n], self.fwd_frag[n] = out, lay
+            fjobs.append(self._pjob(w, out, tb["cmap"], L, 0, L.cout, tb["ktot"], ttot, lay, L._launch_taps(False)[1]))
             for i, rows in enumerate(tb["seg_rows"]):
-                o = torch.empty((rows.numel(), ttot, tb["cout_pad"]), dtype=dtype, device=dev)
-                self.dgrad[(n, i)] = o
-                djobs.append(self._pjob(w, o, rows, L, 1, rows.numel(), tb["cout_pad"], ttot))
+                lay = L.frag_layout(dtype, rows.numel(), tb["cout_pad"], True)
+                if lay:
+                    o = torch.zeros(L.frag_bytes(rows.numel(), tb["cout_pad"], True) // 2, dtype=dtype, device=dev)
+                else:
+                    o = torch.empty((rows.numel(), ttot, tb["cout_pad"]), dtype=dtype, device=dev)
+                self.dgrad[(n, i)], self.dgrad_frag[(n, i)] = o, lay
+                djobs.append(self._pjob(w, o, rows, L, 1, rows.numel(), tb["cout_pad"], ttot, lay, L._launch_taps(True)[1]))
             self.dwp_off[n] = (dwp_total, (L.cout, ttot, tb["ktot"]))
             self.gw_off[n] = (gw_total, tuple(w.shape))
             uj = _lib.UnpackJob()
@@ -161,10 +170,11 @@ class PackSet:
         return total
 
     @staticmethod
-    def _pjob(w, out, cmap, L, mode, R, K, ttot):
+    def _pjob(w, out, cmap, L, mode, R, K, ttot, layout=0, tp=0):
         j = _lib.PackJob()
         j.w, j.out, j.cmap = w.data_ptr(), out.data_ptr(), cmap.data_ptr()
         j.Cout, j.Cin, j.KK, j.mode, j.R, j.K, j.T = L.cout, L.cin, L.kk, mode, R, K, ttot
+        j.layout, j.Tp = layout, (tp or ttot)
         for t, m in enumerate(L.masks):
             j.tapmask[t] = m
         return j
@@ -251,7 +261,7 @@ class DecoderRun:
             odt = torch.float32 if out_f32 else self.dtype
             cp = pad_to(L.cout, vec_of(odt))
             out = (torch.zeros if cp != L.cout else torch.empty)((N, Ho, Wo, cp), dtype=odt, device=dev)
-        L.forward(x, wp, out, act, out_scale, out_scale_n)
+        L.forward(x, wp, out, act, out_scale, out_scale_n, self.packs.fwd_frag[name])
         y = Act(out, act if (not out_map and not out_f32 and out_scale == 1.0 and out_scale_n is None) else ACT_NONE)
         folds = [self._use(s, s.t.dtype == self.dtype) for s in segs]
         if self.record:
@@ -283,7 +293,7 @@ class DecoderRun:
                             raise
                 for i, s in enumerate(segs):
                     if i not in done:
-                        L.dgrad(dz, self.packs.dgrad[(name, i)], i, s.g, accs[i], s.t if folds[i] else None)
+                        L.dgrad(dz, self.packs.dgrad[(name, i)], i, s.g, accs[i], s.t if folds[i] else None, self.packs.dgrad_frag[(name, i)])
                     if folds[i]:
                         s.g_is_dz = True
                 off, shape = self.packs.dwp_off[name]

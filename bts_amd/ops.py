@@ -61,6 +61,41 @@ def lpg_bwd(grad_depth, plane_eq, k, depth_div=1.0, focal=None, out=None):
     return g
 
 
+def _multi_args(eqs, ks, divs):
+    n = len(eqs)
+    B = (C.c_int * n)(*[e.shape[0] for e in eqs])
+    h = (C.c_int * n)(*[e.shape[1] for e in eqs])
+    w = (C.c_int * n)(*[e.shape[2] for e in eqs])
+    kk = (C.c_int * n)(*ks)
+    dv = (C.c_float * n)(*[float(d) for d in divs])
+    return n, B, h, w, kk, dv
+
+
+def lpg_fwd_multi(plane_eqs, ks, depth_divs=None, outs=None):
+    """Several LPG problems (<= 4; e.g. the k = 8 / 4 / 2 heads of one batch) in ONE launch (bts_lpg_fwd_multi)."""
+    for e in plane_eqs:
+        _lib.require_gpu(e)
+        assert e.shape[3] == 4 and e.dtype == torch.float32 and e.is_contiguous()
+    divs = depth_divs or [1.0] * len(ks)
+    if outs is None:
+        outs = [torch.empty((e.shape[0], e.shape[1] * k, e.shape[2] * k), dtype=torch.float32, device=e.device) for e, k in zip(plane_eqs, ks)]
+    n, B, h, w, kk, dv = _multi_args(plane_eqs, ks, divs)
+    call("bts_lpg_fwd_multi", n, (C.c_void_p * n)(*[e.data_ptr() for e in plane_eqs]), (C.c_void_p * n)(*[o.data_ptr() for o in outs]),
+         B, h, w, kk, dv, stream_ptr())
+    return outs
+
+
+def lpg_bwd_multi(grad_depths, plane_eqs, ks, depth_divs=None, outs=None):
+    divs = depth_divs or [1.0] * len(ks)
+    grad_depths = [g.contiguous() for g in grad_depths]
+    if outs is None:
+        outs = [torch.empty_like(e) for e in plane_eqs]
+    n, B, h, w, kk, dv = _multi_args(plane_eqs, ks, divs)
+    call("bts_lpg_bwd_multi", n, (C.c_void_p * n)(*[g.data_ptr() for g in grad_depths]), (C.c_void_p * n)(*[e.data_ptr() for e in plane_eqs]),
+         (C.c_void_p * n)(*[o.data_ptr() for o in outs]), B, h, w, kk, dv, stream_ptr())
+    return outs
+
+
 def lpg_head_fwd(raw, k, max_depth, want_plane=False):
     """raw [B,h,w,>=3] f32 (channel-contiguous) -> depth [B,h*k,w*k] f32 (already / max_depth)."""
     _lib.require_gpu(raw)

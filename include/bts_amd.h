@@ -71,6 +71,17 @@ int bts_lpg_fwd(const float* plane_eq, const float* focal, float* depth,
 int bts_lpg_bwd(const float* grad_depth, const float* plane_eq, const float* focal, float* grad_plane_eq,
                 int batch, int in_h, int in_w, int upratio, float depth_div, bts_stream_t stream);
 
+/* Up to 4 independent LPG problems in ONE launch: the same kernels as bts_lpg_fwd / bts_lpg_bwd, blocks dealt to the problems by
+ * range.  At the training shape (8 x 352 x 1216) one scale moves 14-27 MB -- a few microseconds of HBM time behind ~2 us of launch
+ * boundary --, so a caller that holds the plane equations of several scales (bts.py:227, 241, 255: k = 8, 4, 2 of one batch) gets
+ * them as one stream of work.  Arrays of n entries; semantics, layouts, alignment and focal-less signature as the single calls
+ * (focal is ignored by the reference and has no slot here). */
+int bts_lpg_fwd_multi(int n, const float* const* plane_eq, float* const* depth, const int* batch, const int* in_h, const int* in_w,
+                      const int* upratio, const float* depth_div, bts_stream_t stream);
+int bts_lpg_bwd_multi(int n, const float* const* grad_depth, const float* const* plane_eq, float* const* grad_plane_eq,
+                      const int* batch, const int* in_h, const int* in_w, const int* upratio, const float* depth_div,
+                      bts_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Fused LPG head: raw plane parameters -> sigmoid/angles (bts.py:112-120) -> L2-normalise
  * (bts.py:223-226) -> LPG (bts.py:124-146) -> /max_depth (bts.py:228) in one pass, one thread
@@ -211,6 +222,15 @@ typedef struct {
     const void* w2;
     void* y2;
     int32_t Cout2, y2_stride, accumulate2;
+    /* Layout of `w` (round 5).  0: [Cout][nphase*T][Ktot] as described above.  1: MFMA A-FRAGMENT ORDER, bf16 only, for the
+     * short-K implicit-GEMM kernel that keeps the pixel operand resident in LDS, walks all output-channel tiles and loads the
+     * weights global -> VGPR (csrc/conv_igemm.hip: conv_igemm_res):
+     *     w[phase][row tile rt][chunk c][k-step s][lane l][e],   8 bf16 per lane, s < 4, l < 64,
+     *     rt < 4 * ceil(Cout/128) (row tiles padded to whole 128-row output tiles), c < ceil(T * Ktot / 64),
+     *     element = W[32 rt + (l & 31)][tap][k]  with  (tap, k) = divmod(64 c + 16 s + 8 (l >> 5) + e, Ktot);
+     * rows >= Cout and flattened indices >= T * Ktot are zero.  Written by bts_pack_weight_batch (bts_pack_job_t::layout).
+     * Domain: bf16, Cout > 64, T * Ktot <= 256 (four chunks), a launch the dispatcher sends to the implicit GEMM; BTS_ERR_ARG otherwise. */
+    int32_t w_frag;
 } bts_conv_desc_t;
 /* The descriptor MUST be zero-initialised before it is filled (`bts_conv_desc_t d = {0};` / memset): optional fields (fold_elu_y,
  * w2 / y2 / Cout2 / y2_stride / accumulate2, out_scale_n) are tested against NULL / 0, and fields added at the END of the struct
@@ -276,6 +296,10 @@ typedef struct {
     int32_t Cout, Cin, KK, mode, R, K, T;
     uint16_t tapmask[BTS_MAX_TAP];
     int32_t first_block;
+    /* layout of `out`: 0 = [R][T][K]; 1 = fragment order (bts_conv_desc_t::w_frag; bf16 only); Tp = taps per phase (T = nphase * Tp).
+     * A fragment-order buffer is nphase * 4 ceil(R/128) * ceil(Tp K / 64) * 4096 bytes and must be ZEROED once by the caller: the
+     * kernel writes the R x T x K real entries only. */
+    int32_t layout, Tp;
 } bts_pack_job_t;
 typedef struct {
     int64_t dwp_off; int64_t gw_off;   /* element offsets into the dwp / gw arenas passed to the call */

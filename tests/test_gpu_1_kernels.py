@@ -63,6 +63,44 @@ def test_lpg_op_golden(golden_dir, k):
     assert rel(eq.grad, torch.tensor(g["k%d_geq" % k])) < 1e-4
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 24), (8, 64, 224)], ids=["small", "row_split"])
+def test_lpg_op_multi_matches_single_launches(shape):
+    """bts_lpg_fwd_multi / bts_lpg_bwd_multi: the k = 8 / 4 / 2 problems of one batch in ONE launch -- bit-identical to the three
+    single launches (same kernel bodies, blocks dealt by range), at a size where each cell is one thread and at a size where the
+    k = 8 / 4 problems split a cell's patch rows over several threads (the backward then joins the row partials through LDS); and
+    the golden vectors of the reference through the multi entry."""
+    from bts_amd import ops
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(B * 1000 + W)
+    ks = [8, 4, 2]
+    eqs = [torch.randn(B, H // k, W // k, 4, generator=gen).to(DEV) for k in ks]
+    for e in eqs:
+        e[..., 2] += 3.0                                  # keep the denominators away from zero
+    divs = [80.0, 1.0, 10.0]
+    outs = ops.lpg_fwd_multi(eqs, ks, divs)
+    for e, k, d, o in zip(eqs, ks, divs, outs):
+        assert torch.equal(o, ops.lpg_fwd(e, k, d))
+    gs = [torch.randn(B, H, W, generator=gen).to(DEV) for _ in ks]
+    geqs = ops.lpg_bwd_multi(gs, eqs, ks, divs)
+    for g, e, k, d, ge in zip(gs, eqs, ks, divs, geqs):
+        assert torch.equal(ge, ops.lpg_bwd(g, e, k, d))
+    # two problems only, different batch sizes
+    o2 = ops.lpg_fwd_multi([eqs[2][:1].contiguous(), eqs[0]], [2, 8])
+    assert torch.equal(o2[0], ops.lpg_fwd(eqs[2][:1].contiguous(), 2)) and torch.equal(o2[1], ops.lpg_fwd(eqs[0], 8))
+
+
+def test_lpg_op_multi_golden(golden_dir):
+    from bts_amd import ops
+    g = load(golden_dir, "lpg")
+    ks = [8, 4, 2]
+    eqs = [torch.tensor(g["k%d_eq" % k], device=DEV).permute(0, 2, 3, 1).contiguous() for k in ks]     # golden: NCHW; the op: [B][h][w][4]
+    outs = ops.lpg_fwd_multi(eqs, ks)
+    geqs = ops.lpg_bwd_multi([torch.tensor(g["k%d_gout" % k], device=DEV) for k in ks], eqs, ks)
+    for k, o, ge in zip(ks, outs, geqs):
+        assert rel(o, torch.tensor(g["k%d_out" % k])) < 1e-6
+        assert rel(ge.permute(0, 3, 1, 2), torch.tensor(g["k%d_geq" % k])) < 1e-4
+
+
 @pytest.mark.parametrize("k", [8, 4, 2])
 def test_lpg_head_vs_oracle(k):
     from bts_amd import ops
@@ -174,6 +212,13 @@ CONV_CASES = [
     ("wtr_up", 136, [128], 9, 1, True, (2, 17, 23)),
     ("wtr_1x1", 256, [64, 128, 64], 1, 1, False, (2, 20, 31)),
     ("wtr_dil", 128, [256], 9, 12, False, (1, 29, 40)),
+    # weights in MFMA A-fragment order + resident pixel tile (conv_igemm_res): > 64 output rows, <= 4 chunks of K, on launches that
+    # always take the implicit GEMM: ragged Cout over two output tiles with a half-filled last chunk, 3 + 1 row tiles, several
+    # input segments, the four-phase forward of an up-convolution (4 taps x 64 channels = 4 chunks per phase), many output tiles
+    ("res_up_4ch", 72, [64], 9, 1, True, (2, 9, 13)),
+    ("res_1x1_ragged", 200, [96], 1, 1, False, (2, 17, 19)),
+    ("res_1x1_3seg_5tiles", 600, [64, 128, 64], 1, 1, False, (2, 13, 21)),
+    ("res_1x1_dgrad_wide", 256, [576], 1, 1, False, (2, 13, 21)),
 ]
 
 
@@ -196,10 +241,43 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
     xs_r = [x.clone().requires_grad_(True) for x in xs]
     w_r = w.clone().requires_grad_(True)
     xin = torch.cat(xs_r, 1)
-    if up:
+    if up and dt != torch.bfloat16:
         xin = xin.repeat_interleave(2, 2).repeat_interleave(2, 3)
-    wq = w_r.to(dt).float() if dt == torch.bfloat16 else w_r
-    ref = F.conv2d(xin, wq, padding=dil if kk == 9 else 0, dilation=dil)
+    # (the bf16-rounded weight is the autograd LEAF: differentiating through `.to(bf16).float()` rounds the weight gradient to bf16 on
+    # its way back, and the comparison would measure that rounding -- 3.4e-3 on every case, gpurun r05a -- instead of the kernel)
+    if dt == torch.bfloat16:
+        w_r = w.to(dt).float().requires_grad_(True)
+    wq = w_r
+    if up and dt == torch.bfloat16:
+        # nearest x2 + 3x3 (bts.py:76-79) as the product evaluates it: four 2x2 sub-pixel phases on the LOW-resolution input with the
+        # 3x3 taps that land on the same low-res pixel summed in f32 and THEN rounded to bf16 (one rounding per phase weight instead of
+        # one per tap: the product's operand is bf16(sum), and a tap-wise rounded reference differs from it by 2^-9 per weight --
+        # 2e-3 on the output, gpurun r05b).  Written from the definition: output row 2i + a reads up-sampled rows 2i + a + ky - 1,
+        # i.e. low-res row i + floor((a + ky - 1) / 2).  Straight-through rounding keeps the weight gradient that of the f32 sum.
+        wf = w.clone().requires_grad_(True)                        # un-rounded master weight: the leaf of the weight gradient
+        w_r = wf
+        Hl, Wl = xin.shape[2], xin.shape[3]
+        xp = F.pad(xin, (1, 1, 1, 1))
+        ref = torch.zeros(N, cout, 2 * Hl, 2 * Wl)
+        rows = []
+        for a_ in (0, 1):
+            grp = {}
+            for ky in range(3):
+                grp.setdefault((a_ + ky - 1) // 2, []).append(ky)
+            rows.append(sorted(grp.items()))                       # [(low-res offset, [ky ...]), (offset + 1, [...])]
+        outs_ph = {}
+        for a_ in (0, 1):
+            for b_ in (0, 1):
+                wp_ = torch.stack([torch.stack([sum(wf[:, :, ky, kx] for ky in kys for kx in kxs) for _, kxs in rows[b_]], -1)
+                                   for _, kys in rows[a_]], -2)            # [co][ci][2][2]
+                wp_ = wp_ + (wp_.detach().to(dt).float() - wp_.detach())
+                o = F.conv2d(xp, wp_)                                       # [N][co][Hl+1][Wl+1]: window starts at padded (i, j)
+                oy, ox = rows[a_][0][0] + 1, rows[b_][0][0] + 1            # first offset -1 -> padded start i, 0 -> i + 1
+                outs_ph[(a_, b_)] = o[:, :, oy:oy + Hl, ox:ox + Wl]
+        ref = torch.stack([torch.stack([outs_ph[(a_, 0)], outs_ph[(a_, 1)]], -1) for a_ in (0, 1)], -3)   # [N][co][Hl][2][Wl][2]
+        ref = ref.reshape(N, cout, 2 * Hl, 2 * Wl)
+    else:
+        ref = F.conv2d(xin, wq, padding=dil if kk == 9 else 0, dilation=dil)
     gy = torch.randn(ref.shape, generator=gen)
     if dt == torch.bfloat16:
         gy = gy.to(dt).float()
@@ -223,11 +301,37 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
     print("%s %s fwd err %.3e (max-norm %.3e)" % (name, dt, e, rel(out[..., :cout].float().permute(0, 3, 1, 2), ref)))
     assert e < tol, "fwd"
     assert out[..., cout:].abs().max().item() == 0.0 if cp > cout else True
+    # the same launch with the weights in fragment order (global -> VGPR, conv_igemm_res): same chunks, same k-steps, same MFMA
+    # sequence per accumulator as conv_igemm_dma -- bit-identical, with and without an activation epilogue
+    tb = L.tables(dt, torch.device(DEV))
+    lay = L.frag_layout(dt, cout, tb["ktot"])
+    if lay:
+        from bts_amd._lib import ACT_ELU
+        wpf = L.to_frag(L.pack_fwd(wd_dev, dt), L._launch_taps(False)[0])
+        for act in (ACT_NONE, ACT_ELU):
+            o1, o2 = torch.zeros_like(out), torch.zeros_like(out)
+            L.forward(segs, L.pack_fwd(wd_dev, dt), o1, act)
+            L.forward(segs, wpf, o2, act, w_frag=lay)
+            assert torch.equal(o1, o2), "fragment-order forward (layout %d, act %d)" % (lay, act)
+        _plog("res_fwd", c0=0, k=0, dt=str(dt), name=name, layout=lay, l2=0.0, max=0.0)
 
     dz = _nhwc(gy, dt, v)
     for i, (x, c) in enumerate(zip(xs_r, segc)):
         gx = torch.empty_like(segs[i])
         L.dgrad(dz, L.pack_dgrad(wd_dev, dt, i), i, gx, False)
+        layd = L.frag_layout(dt, segs[i].shape[3], tb["cout_pad"], True)
+        if layd:
+            wdf = L.to_frag(L.pack_dgrad(wd_dev, dt, i), L._launch_taps(True)[0])
+            g2 = torch.empty_like(gx)
+            L.dgrad(dz, wdf, i, g2, False, w_frag=layd)
+            assert torch.equal(g2, gx), "fragment-order dgrad seg %d (layout %d)" % (i, layd)
+            yv0 = _nhwc(torch.randn(x.shape, generator=torch.Generator().manual_seed(5)), dt, v)
+            b0 = _nhwc(torch.randn(x.shape, generator=torch.Generator().manual_seed(6)), dt, v)
+            ga1, ga2 = b0.clone(), b0.clone()
+            L.dgrad(dz, L.pack_dgrad(wd_dev, dt, i), i, ga1, True, yv0)
+            L.dgrad(dz, wdf, i, ga2, True, yv0, w_frag=layd)
+            assert torch.equal(ga1, ga2), "fragment-order dgrad fold+acc seg %d" % i
+            _plog("res_dgrad", c0=0, k=0, dt=str(dt), name=name, layout=layd, seg=i, l2=0.0, max=0.0)
         e = err(gx[..., :c].float().permute(0, 3, 1, 2), x.grad)
         print("%s %s dgrad seg%d err %.3e" % (name, dt, i, e))
         assert e < tol, "dgrad seg %d" % i
@@ -766,7 +870,9 @@ def test_batched_pack_unpack_match_single_layer_kernels(dt):
     the per-layer bts_pack_weight / bts_unpack_wgrad bit for bit: forward operands, data-gradient operands of every
     input segment, and the weight gradients scattered back to PyTorch layout (odd channel counts, phases, dilations)."""
     from bts_amd.decoder import DecoderPlan, PackSet
-    feat, nf = [8, 24, 16, 40, 56], 128
+    # (nf = 256: layers with more than 64 output rows exist, so the bf16 set also holds MFMA-fragment-order operands -- 1x1, dilated,
+    # up-convolution forward / data-gradient in both K orders --, checked against ConvLayer.to_frag's plain-torch statement of it)
+    feat, nf = [8, 24, 16, 40, 56], 256
     plan = DecoderPlan(feat, nf)
     gen = torch.Generator().manual_seed(11)
     P = {k: v.to(DEV) for k, v in O.make_decoder_params(feat, nf, gen).items()}
@@ -776,11 +882,26 @@ def test_batched_pack_unpack_match_single_layer_kernels(dt):
     dwp = torch.randn(ps.dwp_total, generator=gen).to(DEV)
     gw = torch.full((ps.gw_total,), float("nan"), device=DEV)
     ps.unpack_all(dwp, gw)
+    nfrag = set()
     for n, L in plan.layers.items():
         w = P[n + ".weight"]
-        assert torch.equal(ps.fwd[n], L.pack_fwd(w, dt)), n
+        want = L.pack_fwd(w, dt)
+        if ps.fwd_frag[n]:
+            want = L.to_frag(want, L._launch_taps(False)[0])
+            nfrag.add(("fwd", L.kk))
+        assert torch.equal(ps.fwd[n], want), n
         for i in range(len(L.seg_channels)):
-            assert torch.equal(ps.dgrad[(n, i)], L.pack_dgrad(w, dt, i)), (n, i)
+            want = L.pack_dgrad(w, dt, i)
+            if ps.dgrad_frag[(n, i)]:
+                want = L.to_frag(want, L._launch_taps(True)[0])
+                nfrag.add(("dgrad", L.kk))
+            assert torch.equal(ps.dgrad[(n, i)], want), (n, i)
+    if dt == torch.bfloat16:
+        from bts_amd.conv import _res_enabled
+        assert not _res_enabled() or {("fwd", 1), ("dgrad", 1)} <= nfrag, nfrag       # 1x1 layers with K <= 256: forward and data gradient
+    else:
+        assert not nfrag
+    for n, L in plan.layers.items():
         off, shape = ps.dwp_off[n]
         goff, gshape = ps.gw_off[n]
         want = L.unpack_wgrad(dwp[off:off + shape[0] * shape[1] * shape[2]].view(shape), dt)
