@@ -18,6 +18,23 @@
 #include "common.h"
 #include "conv_common.h"
 
+#ifdef BTS_TRACE
+// Diagnostic build only (tools/build_trace_lib.sh; never part of libbts_amd.so): s_memtime stamps of a few waves of conv_igemm_dma's
+// default schedule -- top of chunk / DMA landed / barrier passed / last MFMA issued -- to see where a chunk's time goes.
+__device__ unsigned long long g_bts_trace[16 * 2 * 64 * 4];
+extern "C" int bts_trace_dump(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_bts_trace), sizeof(g_bts_trace)) == hipSuccess ? 0 : -2;
+}
+extern "C" int bts_trace_clear() {
+    static unsigned long long z[16 * 2 * 64 * 4];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bts_trace), z, sizeof(z)) == hipSuccess ? 0 : -2;
+}
+// stamps go to LDS (a global store per stamp would sit in the vmcnt queue the loop waits on) and leave after the loop
+#define BTS_STAMP(slot) do { if (tr_on && chunk < 64) { tr_lds[chunk * 4 + (slot)] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define BTS_STAMP(slot) do { } while (0)
+#endif
+
 namespace {
 
 using namespace bts_conv;
@@ -234,10 +251,20 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) { prep_chunk(s); fire_chunk(s); }
     int rbuf = 0, wbuf = NS - 1;
+#ifdef BTS_TRACE
+    const int tr_wg = (int)blockIdx.x / 29;                 // 16 workgroups spread over the grid (when it has >= 464 of them)
+    const bool tr_on = (blockIdx.x % 29) == 0 && tr_wg < 16 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 3);
+    unsigned long long* tr_base = g_bts_trace + (size_t)((tr_wg & 15) * 2 + (wave == 3 ? 1 : 0)) * 64 * 4;
+    __shared__ unsigned long long tr_smem[2 * 64 * 4];
+    unsigned long long* tr_lds = tr_smem + (wave == 3 ? 256 : 0);
+#endif
     for (int chunk = 0; chunk < nchunks; ++chunk) {
+        BTS_STAMP(0);
         prep_chunk(chunk + NS - 1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G) : "memory");   // this wave's part of `chunk` has landed
+        BTS_STAMP(1);
         __builtin_amdgcn_s_barrier();                                          // everyone's has; buffer wbuf is free
+        BTS_STAMP(2);
         const char* sT = smem + rbuf * BUF;
         if constexpr (PF == 8 && TM == 2 && TN == 2) {
             // Fine interleave (the lever on conv_halo_wide: +10 % there): the reads of k-step s+1 and the chunk's 8 DMA issues sit
@@ -278,6 +305,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             mm(1, 0, 0); mm(1, 0, 1); mm(1, 1, 0); mm(1, 1, 1);
             __builtin_amdgcn_s_setprio(0);
+            BTS_STAMP(3);
         } else {
             u32x4_t fa[2][TM], fb[2][TN];
             // k-step 0 fragments first (their LDS latency overlaps the DMA issue), then one k-step of read-ahead
@@ -306,6 +334,10 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
         wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the zero-page tail groups before LDS is released
+#ifdef BTS_TRACE
+    if (tr_on)
+        for (int i = 0; i < 256 && i < nchunks * 4; ++i) tr_base[i] = tr_lds[i];
+#endif
     conv_epilogue<T, WR, WC, TM, TN, EPI>(a, acc, co_tile, px_tile, phase, wr, wc, frow, fk);
 }
 

@@ -25,7 +25,9 @@ __device__ __forceinline__ float lpg_eval(float n1, float n2, float n3, float n4
 
 // ---- LPG op boundary: plane_eq [B][h][w][4] -> depth [B][hk][wk] ---------------------------
 // thread = (cell, group of RPT patch rows); lanes run over the cells of one coarse row
-template <int K, int RPT>
+// NT: the full-resolution map is written (forward) / read (backward) with the nontemporal hint -- it streams through once, and a
+// write-allocating store stream measured 3.1 TB/s against 3.9-4.5 with the hint at the training shape (gpurun r05g / r05h)
+template <int K, int RPT, bool NT = true>
 __device__ __forceinline__ void lpg_fwd_body(const float* __restrict__ eq, float* __restrict__ depth,
                                              int cells, int h, int w, float div, long block) {
     constexpr int NR = K / RPT;
@@ -51,9 +53,14 @@ __device__ __forceinline__ void lpg_fwd_body(const float* __restrict__ eq, float
         float* p = out + (size_t)r * w * K;
         if (K >= 4) {
 #pragma unroll
-            for (int c = 0; c < K; c += 4) *(f32x4_t*)(p + c) = f32x4_t{o[c], o[c + 1], o[c + 2], o[c + 3]};
+            for (int c = 0; c < K; c += 4) {
+                const f32x4_t t4 = {o[c], o[c + 1], o[c + 2], o[c + 3]};
+                if (NT) __builtin_nontemporal_store(t4, (f32x4_t*)(p + c)); else *(f32x4_t*)(p + c) = t4;
+            }
         } else {
-            *(float2*)p = make_float2(o[0], o[1]);
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            const f32x2_t t2 = {o[0], o[1]};
+            if (NT) __builtin_nontemporal_store(t2, (f32x2_t*)p); else *(f32x2_t*)p = t2;
         }
     }
 }
@@ -61,12 +68,12 @@ __device__ __forceinline__ void lpg_fwd_body(const float* __restrict__ eq, float
 template <int K, int RPT>
 __global__ __launch_bounds__(256) void lpg_fwd_kernel(const float* __restrict__ eq, float* __restrict__ depth,
                                                       int cells, int h, int w, float div) {
-    lpg_fwd_body<K, RPT>(eq, depth, cells, h, w, div, blockIdx.x);
+    lpg_fwd_body<K, RPT, true>(eq, depth, cells, h, w, div, blockIdx.x);
 }
 
 // true gradient of out = n4 / (den * div).  Workgroup = (256 / NR) consecutive cells x NR row groups (thread = row group * CPB +
 // cell): each thread accumulates its RPT rows, the NR partials of a cell are summed through LDS in row order.
-template <int K, int RPT>
+template <int K, int RPT, bool NT = true>
 __device__ __forceinline__ void lpg_bwd_body(const float* __restrict__ gdepth, const float* __restrict__ eq,
                                              float* __restrict__ geq, int cells, int h, int w, float div, long block, f32x4_t* part) {
     constexpr int NR = K / RPT, CPB = 256 / NR;
@@ -87,11 +94,12 @@ __device__ __forceinline__ void lpg_bwd_body(const float* __restrict__ gdepth, c
             if (K >= 4) {
 #pragma unroll
                 for (int cc = 0; cc < K; cc += 4) {
-                    const f32x4_t tt = *(const f32x4_t*)(p + cc);
+                    const f32x4_t tt = NT ? __builtin_nontemporal_load((const f32x4_t*)(p + cc)) : *(const f32x4_t*)(p + cc);
                     g[cc] = tt.x; g[cc + 1] = tt.y; g[cc + 2] = tt.z; g[cc + 3] = tt.w;
                 }
             } else {
-                const float2 tt = *(const float2*)p;
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                const f32x2_t tt = NT ? __builtin_nontemporal_load((const f32x2_t*)p) : *(const f32x2_t*)p;
                 g[0] = tt.x; g[1] = tt.y;
             }
 #pragma unroll
@@ -125,7 +133,7 @@ template <int K, int RPT>
 __global__ __launch_bounds__(256) void lpg_bwd_kernel(const float* __restrict__ gdepth, const float* __restrict__ eq,
                                                       float* __restrict__ geq, int cells, int h, int w, float div) {
     __shared__ f32x4_t part[256];
-    lpg_bwd_body<K, RPT>(gdepth, eq, geq, cells, h, w, div, blockIdx.x, part);
+    lpg_bwd_body<K, RPT, true>(gdepth, eq, geq, cells, h, w, div, blockIdx.x, part);
 }
 
 // ---- several LPG problems in ONE launch (bts_lpg_fwd_multi / bts_lpg_bwd_multi) --------------------------------------------
@@ -164,7 +172,10 @@ __global__ __launch_bounds__(256) void lpg_multi_kernel(const LpgMulti m) {
     const long block = (long)blockIdx.x - q.first[0];
     const int k = q.k[0], rpt = q.rpt[0];
 #define FORM(KK, RR) if (k == KK && rpt == RR) { lpg_multi_one<BWD, KK, RR>(q, 0, block, part); return; }
-    FORM(8, 8) FORM(8, 4) FORM(8, 2) FORM(8, 1) FORM(4, 4) FORM(4, 2) FORM(4, 1) FORM(2, 2) FORM(2, 1)
+    // (backward: at most 2 patch rows per thread -- the 4- and 8-row forms need 152 / 256 registers and would set the occupancy of the
+    // whole launch: the first version ran the three backward problems at 2.2 TB/s against 3.2 for three single launches)
+    if constexpr (!BWD) { FORM(8, 8) FORM(8, 4) FORM(4, 4) }
+    FORM(8, 2) FORM(8, 1) FORM(4, 2) FORM(4, 1) FORM(2, 2) FORM(2, 1)
 #undef FORM
 }
 
@@ -435,12 +446,17 @@ __global__ __launch_bounds__(256) void silog_bwd_kernel(const float* __restrict_
     }
 }
 
-// rows per thread: the whole patch when that already gives >= 2^19 threads (two full waves of workgroups per CU), else the
-// largest split that does, else one row per thread
+// Rows per thread.  Large maps: the whole patch per thread as long as that leaves >= 2^19 threads (two full waves of workgroups per
+// CU).  Small maps: FOUR rows (forward) / TWO rows (backward) per thread, not one -- at the training shape (8 x 352 x 1216: 53 504
+// cells at k = 8) one row per thread fills the chip with threads that have 32 bytes each in flight and ran 2.7-3.3 TB/s; 4 / 2 rows
+// measured 4.5 / 4.2 TB/s (gpurun r05h: forward 1 / 2 / 4 / 8 rows: 18.1 / 13.7 / 13.3 / 17.3 us for the three scales together;
+// backward 1 / 2 rows: 23.7 / 18.5).  The backward stops at two rows: its 4- and 8-row forms need 152 / 256 registers.
 template <int K>
-int lpg_rows_per_thread(int cells) {
+int lpg_rows_per_thread(int cells, bool bwd) {
+    const int floor_rpt = bwd ? (K < 2 ? K : 2) : (K < 4 ? K : 4);
     int rpt = K;
-    while (rpt > 1 && (long)cells * (K / rpt) < (1l << 19)) rpt >>= 1;
+    while (rpt > floor_rpt && (long)cells * (K / rpt) < (1l << 19)) rpt >>= 1;
+    if (bwd && rpt > 2 && (long)cells * (K / rpt) < (1l << 20)) rpt = 2;      // (the wide backward forms only where threads abound)
     return rpt;
 }
 template <int K, int RPT>
@@ -457,7 +473,7 @@ int lpg_bwd_go(const float* g, const float* eq, float* geq, int cells, int h, in
 }
 template <int K>
 int lpg_fwd_launch(const float* eq, float* depth, int cells, int h, int w, float div, hipStream_t st) {
-    const int rpt = lpg_rows_per_thread<K>(cells);
+    const int rpt = lpg_rows_per_thread<K>(cells, false);
     if constexpr (K >= 8) { if (rpt == 8) return lpg_fwd_go<K, 8>(eq, depth, cells, h, w, div, st); }
     if constexpr (K >= 4) { if (rpt == 4) return lpg_fwd_go<K, 4>(eq, depth, cells, h, w, div, st); }
     if (rpt == 2) return lpg_fwd_go<K, 2>(eq, depth, cells, h, w, div, st);
@@ -465,7 +481,7 @@ int lpg_fwd_launch(const float* eq, float* depth, int cells, int h, int w, float
 }
 template <int K>
 int lpg_bwd_launch(const float* g, const float* eq, float* geq, int cells, int h, int w, float div, hipStream_t st) {
-    const int rpt = lpg_rows_per_thread<K>(cells);
+    const int rpt = lpg_rows_per_thread<K>(cells, true);
     if constexpr (K >= 8) { if (rpt == 8) return lpg_bwd_go<K, 8>(g, eq, geq, cells, h, w, div, st); }
     if constexpr (K >= 4) { if (rpt == 4) return lpg_bwd_go<K, 4>(g, eq, geq, cells, h, w, div, st); }
     if (rpt == 2) return lpg_bwd_go<K, 2>(g, eq, geq, cells, h, w, div, st);
@@ -518,7 +534,8 @@ static int lpg_multi_fill(LpgMulti& m, int n, const int* B, const int* h, const 
         BTS_CHECK_ARG(B[i] > 0 && h[i] > 0 && w[i] > 0 && (k[i] == 2 || k[i] == 4 || k[i] == 8) && div[i] != 0.f);
         BTS_CHECK_ARG((long)B[i] * h[i] * w[i] < (1l << 31));
         const int cells = B[i] * h[i] * w[i];
-        const int rpt = k[i] == 8 ? lpg_rows_per_thread<8>(cells) : (k[i] == 4 ? lpg_rows_per_thread<4>(cells) : lpg_rows_per_thread<2>(cells));
+        int rpt = k[i] == 8 ? lpg_rows_per_thread<8>(cells, bwd) : (k[i] == 4 ? lpg_rows_per_thread<4>(cells, bwd) : lpg_rows_per_thread<2>(cells, bwd));
+        if (bwd && rpt > 2) rpt = 2;                   // the backward forms lpg_multi_kernel instantiates
         m.cells[i] = cells; m.h[i] = h[i]; m.w[i] = w[i]; m.k[i] = k[i]; m.rpt[i] = rpt; m.div[i] = div[i];
         m.first[i] = total;
         const int nr = k[i] / rpt;

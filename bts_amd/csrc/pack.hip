@@ -193,11 +193,16 @@ __global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const bts_unpac
         float acc[9];
 #pragma unroll
         for (int sidx = 0; sidx < 9; ++sidx) acc[sidx] = 0.f;
-        for (int t = 0; t < Tn; ++t) {
-            const float v = dwp[((size_t)co * Tn + t) * K + k];
-            const uint32_t mask = mask_s[t];
+        // all taps' loads in flight before the first use (a run-time trip count kept them one round trip each)
+        float v[BTS_MAX_TAP];
 #pragma unroll
-            for (int sidx = 0; sidx < 9; ++sidx) if (mask & (1u << sidx)) acc[sidx] += v;
+        for (int t = 0; t < BTS_MAX_TAP; ++t) v[t] = t < Tn ? __builtin_nontemporal_load(dwp + ((size_t)co * Tn + t) * K + k) : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < BTS_MAX_TAP; ++t) {
+            const uint32_t mask = t < Tn ? mask_s[t] : 0u;
+#pragma unroll
+            for (int sidx = 0; sidx < 9; ++sidx) if (mask & (1u << sidx)) acc[sidx] += v[t];
         }
 #pragma unroll
         for (int sidx = 0; sidx < 9; ++sidx) if (sidx < KK) stage[tid * KK + sidx] = acc[sidx];
