@@ -529,7 +529,9 @@ struct BwdLayer {
 // 512-entry register file (the LDS footprint -- 48 KiB of fragments + 60 KiB of transpose scratch -- allows one workgroup per
 // CU anyway); the narrower chains keep two.
 template <int C0, int KUP>
-__global__ __launch_bounds__(256, (C0 >= 128 ? 1 : 2)) void lpg_chain_bwd_kernel(const ChainBwdK a) {
+// (r5: three workgroups per CU for the 32- / 16-channel k = 1 chains -- 168 registers without a spill; two left the launcher's
+// grid of 4 x CUs running as two half-filled rounds)
+__global__ __launch_bounds__(256, (C0 >= 128 ? 1 : ((C0 <= 32 && KUP == 1) || C0 <= 16 ? 3 : 2))) void lpg_chain_bwd_kernel(const ChainBwdK a) {
     constexpr int NOUT = KUP == 1 ? 1 : 3;
     constexpr int NTOT = bwd_dw_tiles<C0, NOUT>();
     constexpr int SROWS = bwd_scr_rows<C0, NOUT>();
@@ -584,7 +586,10 @@ __global__ __launch_bounds__(256, (C0 >= 128 ? 1 : 2)) void lpg_chain_bwd_kernel
                     for (int p2 = 0; p2 < 2; ++p2) {
                         const int ch = 32 * tn + 8 * (2 * p2 + g);
                         if (a.dx_accumulate) oldw[p2] = *(const u32x4_t*)(px + ch * 2);
-                        if (a.fold_elu) xw[p2] = *(const u32x4_t*)((const char*)a.x + ((size_t)t.cell * a.x_stride + ch) * 2);
+                        // the ELU output the fold needs is the layer-0 input fragment this lane already holds: natural K order puts
+                        // channels 16 s + 8 g + 0..7 in in.v[s], and after the permlane swap the lane owns exactly channels
+                        // 32 tn + 8 (2 p2 + g) + 0..7 = fragment s = 2 tn + p2 (r5: was a second 16-byte read of x per 8 channels)
+                        if (a.fold_elu) xw[p2] = in.v[2 * tn + p2];
                     }
 #pragma unroll
                     for (int p2 = 0; p2 < 2; ++p2)
@@ -843,7 +848,7 @@ int launch_chain_bwd(const ChainBwdK& k, hipStream_t st) {
     if (ensure_dyn_lds((const void*)kern, lds, lds_set) != BTS_OK) return BTS_ERR_LAUNCH;
     const long ntiles = (k.cells + 31) / 32;
     long blocks = (ntiles + 3) / 4;
-    int per_cu = C0 >= 64 ? 2 : 4;                   // resident workgroups per CU allowed by registers ...
+    int per_cu = C0 >= 64 ? 2 : (((C0 <= 32 && KUP == 1) || C0 <= 16) ? 3 : 2);      // resident workgroups per CU allowed by registers ...
     if (per_cu > 160 * 1024 / lds) per_cu = 160 * 1024 / lds;      // ... and by LDS
     if (blocks > 256l * per_cu) blocks = 256l * per_cu;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), (size_t)lds, st, k);

@@ -31,6 +31,8 @@ def family(name):
     if m:
         wr, wc, tm, tn = map(int, m.groups())
         return "conv_igemm_dma<bf16,%dx%d>" % (wr * tm * 32, wc * tn * 32)
+    if n.startswith("conv_igemm_res<"):
+        return "conv_igemm_res<bf16,128xN>"
     m = re.match(r"conv_wgrad_ring(?:_group)?<(\d), (\d)", n)      # the grouped launches are the same kernel body: one family
     if m:
         return "conv_wgrad_ring<bf16,%dx%d>" % (int(m.group(1)) * 64, int(m.group(2)) * 64)
@@ -68,15 +70,24 @@ def family(name):
     return None
 
 
+# families whose C-ABI call is several kernels: the CALL count is the dispatch count of one marker kernel (the counter bytes of all of
+# the family's kernels are summed and divided by it, so the figure compares with bench.py's per-call algorithmic bytes)
+CALL_MARKER = {"bn_bwd": "bn_bwd_apply", "bn_stats": "bn_stats_partial"}
+
+
 def load(path, counter):
-    per = defaultdict(list)
+    """family -> [sum of the counter over every kernel of the family, number of C-ABI calls]"""
+    per = defaultdict(lambda: [0.0, 0])
     import gzip
     for r in csv.DictReader(gzip.open(path, "rt") if path.endswith(".gz") else open(path)):
         if r.get("Counter_Name") != counter:
             continue
         f = family(r["Kernel_Name"])
         if f:
-            per[f].append(float(r["Counter_Value"]))
+            per[f][0] += float(r["Counter_Value"])
+            n = re.sub(r"\(anonymous namespace\)::|bts_conv::|^void ", "", r["Kernel_Name"])
+            if f not in CALL_MARKER or n.startswith(CALL_MARKER[f]):
+                per[f][1] += 1
     return per
 
 
@@ -102,20 +113,22 @@ def main():
     fetch, write = load(fpath, "FETCH_SIZE"), load(wpath, "WRITE_SIZE")
     table = {}
     for fam in sorted(set(fetch) & set(write)):
-        nf, nw = len(fetch[fam]), len(write[fam])
-        rd = 2.0 * 1024.0 * sum(fetch[fam]) / nf
-        wr = 1024.0 * sum(write[fam]) / nw
+        nf, nw = fetch[fam][1], write[fam][1]
+        if nf == 0 or nw == 0:
+            continue
+        rd = 2.0 * 1024.0 * fetch[fam][0] / nf
+        wr = 1024.0 * write[fam][0] / nw
         table[fam] = {"bytes_per_launch": round(rd + wr), "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                       "launches_fetch_pass": nf, "launches_write_pass": nw,
                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --graph 0; FETCH_SIZE x2 "
                                 "(gfx950 tallies 128-B requests at 64 B), KiB -> bytes; fabric-side, Infinity-Cache hits included"}
-        if fam in alg:      # (bn_bwd / bn_stats: the counter figure is per KERNEL launch, the algorithmic one per C-ABI call -- see _meta)
+        if fam in alg:
             table[fam]["alg_bytes_per_launch"] = round(alg[fam])
             table[fam]["traffic_over_algorithmic"] = round((rd + wr) / alg[fam], 2)
     table["_meta"] = {"library_md5": md5, "config": "both passes with BTS_CONV_WIDE=0 (rocprofv3 aborts a --pmc pass at conv_halo_wide's first "
                       "dispatch): the wide 3x3 layers run on conv_igemm_dma here, so that family covers more launches per step than in the timed step",
-                      "note": "bn_bwd = reduction + final + apply kernels of one call, bn_stats = partial + final: "
-                      "per KERNEL launch here, where bench.py's families count C-ABI calls"}
+                      "note": "every figure is per C-ABI CALL (bench.py's unit): bn_bwd = reduction + final + apply kernels of one call, "
+                      "bn_stats = partial + final -- their kernels' counters are summed per call"}
     with open(out, "w") as f:
         json.dump(table, f, indent=1)
     for k, v in table.items():
