@@ -587,22 +587,21 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
             k.kmajor = 0;                                  // tap-major K order: the fragment layout's
             const int nchunks = (k.T * k.KV + 7) >> 3;
             if (k.Cout <= 64 || k.wfrag != 1 || nchunks > RES_MAX_CHUNKS) return BTS_ERR_ARG;
-            static const int layout = [] { const char* e = getenv("BTS_RES_LAYOUT"); return e ? atoi(e) : 0; }();
             const int epi = epilogue_form(k, BF, true);
-            auto go_res = [&](auto kern, int bn) {
+            // 2 x 2 waves of 64 x 64 on a 128-pixel tile.  Measured against it (gpurun r05c / r05d, removed): 4 x 1 waves of 32 x 128
+            // (263 vs 272 us over the eight launches: within the box spread, twice the fragment reads) and 64-pixel tiles with three
+            // workgroups per CU (338 us: half the MACs per weight fragment loaded)
+            auto go_res = [&](auto kern) {
                 k.n_co_tiles = ceil_div(k.Cout, 128);
-                k.n_px_tiles = ceil_div(k.M, bn);
+                k.n_px_tiles = ceil_div(k.M, 128);
                 hipLaunchKernelGGL(kern, dim3(k.n_px_tiles, k.nphase), dim3(256), 0, st, k);
             };
-#define BTS_RES_(E) do { if (layout == 1) go_res(conv_igemm_res<4, 1, 1, 4, E>, 128); else if (layout == 2) go_res(conv_igemm_res<2, 2, 2, 1, E>, 64); \
-                         else go_res(conv_igemm_res<2, 2, 2, 2, E>, 128); } while (0)
-            if (epi == 1) BTS_RES_(1);
-            else if (epi == 2) BTS_RES_(2);
-            else if (epi == 3) BTS_RES_(3);
-            else if (epi == 4) BTS_RES_(4);
-            else if (epi == 5) BTS_RES_(5);
-            else BTS_RES_(0);
-#undef BTS_RES_
+            if (epi == 1) go_res(conv_igemm_res<2, 2, 2, 2, 1>);
+            else if (epi == 2) go_res(conv_igemm_res<2, 2, 2, 2, 2>);
+            else if (epi == 3) go_res(conv_igemm_res<2, 2, 2, 2, 3>);
+            else if (epi == 4) go_res(conv_igemm_res<2, 2, 2, 2, 4>);
+            else if (epi == 5) go_res(conv_igemm_res<2, 2, 2, 2, 5>);
+            else go_res(conv_igemm_res<2, 2, 2, 2, 0>);
             BTS_LAUNCH_CHECK();
             return BTS_OK;
         }

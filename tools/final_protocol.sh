@@ -15,7 +15,9 @@ export TMPDIR=/tmp
 R=$PWD
 MD5=$(md5sum bts_amd/lib/libbts_amd.so | cut -d' ' -f1)
 echo "$MD5  bts_amd/lib/libbts_amd.so" > $O/${T}_pytest_gpu.log
+rm -f $O/parity_bounds.jsonl
 run_to 500 python -m pytest tests -m gpu -x -q >> $O/${T}_pytest_gpu.log 2>&1
+cp $O/parity_bounds.jsonl $O/${T}_parity_bounds.jsonl 2> /dev/null      # measured distance of every tightened parity check to its bound
 run_to 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" >> $O/${T}_pytest_gpu.log 2>&1
 tail -3 $O/${T}_pytest_gpu.log
 run_to 420 python bench.py --steps 20 --warmup 5 --dump-launches $O/${T}_launches.json > $O/${T}_bench_bf16.json 2> $O/${T}_bench_bf16.err
@@ -42,6 +44,8 @@ cd $R
 BTS_CONV_WIDE=0 run_to 150 python bench.py $A --steps 5 --warmup 2 --dump-launches $O/${T}_launches_wide0.json > /dev/null 2>&1
 python tools/pmc_traffic.py $O/${T}_pmc_FETCH_SIZE.csv $O/${T}_pmc_WRITE_SIZE.csv $O/${T}_pmc_traffic.json $MD5 $O/${T}_launches_wide0.json > $O/${T}_pmc_traffic.txt 2>&1; tail -12 $O/${T}_pmc_traffic.txt
 python tools/pmc_sq.py $O/${T}_pmc_sq.csv $O/${T}_pmc_sq.json $MD5 $O/${T}_launches_wide0.json > $O/${T}_pmc_sq.txt 2>&1; tail -12 $O/${T}_pmc_sq.txt
+# chunk timeline of conv_igemm_dma on the diagnostic build (tools/build_trace_lib.sh must have been run before the call: the .so travels)
+[ -f bts_amd/lib/libbts_amd_trace.so ] && run_to 120 python tools/trace_igemm.py > $O/${T}_trace_igemm.jsonl 2> /dev/null
 # the counter CSVs are large: keep the summaries, drop the raw files beyond the 64 MiB the call may bring back
 gzip -9 -f $O/${T}_pmc_FETCH_SIZE.csv $O/${T}_pmc_WRITE_SIZE.csv $O/${T}_pmc_sq.csv 2> /dev/null
 ls -la $O | grep ${T}_ | head -40
