@@ -320,6 +320,7 @@ __device__ __forceinline__ void store_block32_plain_bf16(const ConvK& a, size_t 
         uint32_t b0 = pack_bf16x2(v[8 * p + 4], v[8 * p + 5]), b1 = pack_bf16x2(v[8 * p + 6], v[8 * p + 7]);
         const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
         const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        // (nontemporal stores for the large full-resolution outputs measured no difference: gpurun r05k)
         *(u32x4_t*)((uint16_t*)a.y + opix * a.y_stride + cb + 8 * (2 * p + fk)) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
     }
 }

@@ -3,9 +3,11 @@
 #   bash tools/final_protocol.sh <tag>
 # pytest -m gpu + smoke, the bench lines of every BASELINE configuration (the default line carries the f32 child, the eager figure, parity
 # and cpu_baseline), rocprofv3 kernel statistics of the bench command, the FETCH_SIZE / WRITE_SIZE passes behind profiles/pmc_traffic.json
-# and one SQ pass (MFMA-busy / wait counters).  The three counter passes run with BTS_CONV_WIDE=0: rocprofv3 aborts a --pmc pass at
-# conv_halo_wide's first dispatch (profiles/r03_pmc_fetch_abort_with_halo_wide.log; static or dynamic LDS, excluded by regex or not --
-# gpurun r04c / r04d), and the aborted profiler leaves a process behind that holds the call until its limit.  Every step runs in its own
+# and one SQ pass (MFMA-busy / wait counters).  The three counter passes run with BTS_CONV_WIDE=0 BTS_RES=0: rocprofv3 aborts the FETCH_SIZE
+# pass (HSA_STATUS_ERROR_INVALID_PACKET_FORMAT) at conv_halo_wide's first dispatch (profiles/r03_pmc_fetch_abort_with_halo_wide.log; static
+# or dynamic LDS, excluded by regex or not -- gpurun r04c / r04d) and, since round 5, at conv_igemm_res's (gpurun r05p1: aborted with it, r05k:
+# passes without it; the WRITE_SIZE and SQ passes do not mind either kernel), and the aborted profiler leaves a process behind that holds
+# the call until its limit.  Every step runs in its own
 # process group with a hard kill (tools/gpu_guard.sh).
 . tools/gpu_guard.sh
 T=${1:-final}
@@ -32,16 +34,16 @@ run_to 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${T}_pro
 cp $(find /tmp/${T}_prof -name '*kernel_stats.csv' | head -1) $R/$O/${T}_bench_kernel_stats.csv 2> /dev/null
 P="--graph 0 --steps 3 --warmup 1 --no-kernel-events $A"
 for c in FETCH_SIZE WRITE_SIZE; do
-  BTS_CONV_WIDE=0 run_to 240 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/${T}_pmc_$c -o b -- python $R/bench.py $P > $R/$O/${T}_pmc_$c.out 2> $R/$O/${T}_pmc_$c.err
+  BTS_CONV_WIDE=0 BTS_RES=0 run_to 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/${T}_pmc_$c -o b -- python $R/bench.py $P > $R/$O/${T}_pmc_$c.out 2> $R/$O/${T}_pmc_$c.err
   echo "pmc $c rc=$?"
   cp $(find /tmp/${T}_pmc_$c -name '*counter_collection.csv' | head -1) $R/$O/${T}_pmc_$c.csv 2> /dev/null
 done
-BTS_CONV_WIDE=0 run_to 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d /tmp/${T}_pmc_sq -o b -- python $R/bench.py $P > $R/$O/${T}_pmc_sq.out 2> $R/$O/${T}_pmc_sq.err
+BTS_CONV_WIDE=0 BTS_RES=0 run_to 150 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d /tmp/${T}_pmc_sq -o b -- python $R/bench.py $P > $R/$O/${T}_pmc_sq.out 2> $R/$O/${T}_pmc_sq.err
 echo "pmc SQ rc=$?"
 cp $(find /tmp/${T}_pmc_sq -name '*counter_collection.csv' | head -1) $R/$O/${T}_pmc_sq.csv 2> /dev/null
 cd $R
-# algorithmic bytes per launch of every family IN THE CONFIGURATION OF THE COUNTER PASSES (BTS_CONV_WIDE=0), for the traffic / algorithmic ratio
-BTS_CONV_WIDE=0 run_to 150 python bench.py $A --steps 5 --warmup 2 --dump-launches $O/${T}_launches_wide0.json > /dev/null 2>&1
+# algorithmic bytes per launch of every family IN THE CONFIGURATION OF THE COUNTER PASSES (BTS_CONV_WIDE=0 BTS_RES=0), for the traffic / algorithmic ratio
+BTS_CONV_WIDE=0 BTS_RES=0 run_to 150 python bench.py $A --steps 5 --warmup 2 --dump-launches $O/${T}_launches_wide0.json > /dev/null 2>&1
 python tools/pmc_traffic.py $O/${T}_pmc_FETCH_SIZE.csv $O/${T}_pmc_WRITE_SIZE.csv $O/${T}_pmc_traffic.json $MD5 $O/${T}_launches_wide0.json > $O/${T}_pmc_traffic.txt 2>&1; tail -12 $O/${T}_pmc_traffic.txt
 python tools/pmc_sq.py $O/${T}_pmc_sq.csv $O/${T}_pmc_sq.json $MD5 $O/${T}_launches_wide0.json > $O/${T}_pmc_sq.txt 2>&1; tail -12 $O/${T}_pmc_sq.txt
 # chunk timeline of conv_igemm_dma on the diagnostic build (tools/build_trace_lib.sh must have been run before the call: the .so travels)

@@ -125,8 +125,9 @@ def main():
         if fam in alg:
             table[fam]["alg_bytes_per_launch"] = round(alg[fam])
             table[fam]["traffic_over_algorithmic"] = round((rd + wr) / alg[fam], 2)
-    table["_meta"] = {"library_md5": md5, "config": "both passes with BTS_CONV_WIDE=0 (rocprofv3 aborts a --pmc pass at conv_halo_wide's first "
-                      "dispatch): the wide 3x3 layers run on conv_igemm_dma here, so that family covers more launches per step than in the timed step",
+    table["_meta"] = {"library_md5": md5, "config": "both passes with BTS_CONV_WIDE=0 BTS_RES=0 (rocprofv3 aborts the FETCH_SIZE pass at the first dispatch of "
+                      "conv_halo_wide or conv_igemm_res): the wide 3x3 layers and the short-K 1x1 launches run on conv_igemm_dma here, so that family covers more "
+                      "launches per step than in the timed step",
                       "note": "every figure is per C-ABI CALL (bench.py's unit): bn_bwd = reduction + final + apply kernels of one call, "
                       "bn_stats = partial + final -- their kernels' counters are summed per call"}
     with open(out, "w") as f:
