@@ -153,7 +153,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.argtypes = args
         fn.restype = C.c_long if name in _LONG_RET else C.c_int
-    if lib.bts_abi_version() != 2:
+    if lib.bts_abi_version() != 3:
         raise BtsAmdError("libbts_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BTS_AMD_ABI_VERSION 2
+#define BTS_AMD_ABI_VERSION 3
 
 enum { BTS_F32 = 0, BTS_BF16 = 1 };
 enum { BTS_ACT_NONE = 0, BTS_ACT_ELU = 1, BTS_ACT_SIGMOID = 2, BTS_ACT_RELU = 3 };

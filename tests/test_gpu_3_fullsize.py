@@ -241,6 +241,66 @@ def test_decoder_parity_at_bench_config(cfg, dt):
     assert not bad, bad
 
 
+def test_decoder_gradients_f64_arbitrated():
+    """WHICH side of the f32 gradient comparison above carries the 1-2e-3 behind the dense-ASPP ReLUs?  The oracle's formulas in f64 on
+    the device are the arbiter; the product's f32 decoder (fused f32 chains included) and torch's own f32 evaluation of the same
+    formulas are both measured against it, tensor by tensor (L2-relative), at the benchmarked resolution and widths (2 of the 8
+    images: the f64 convolutions of the full batch would take minutes).  Bar: every gradient of the product is within 1e-4 of the
+    f64 result, or no further from it than 2x what torch's f32 evaluation is -- i.e. the product is as close to the truth as an f32
+    evaluation of bts.py:196-266 under autograd can be expected to be.  (Until round 5 this argument lived outside the suite:
+    tools/parity_probe.py, profiles/r02_parity_probe_c3.json.)"""
+    from bts_amd.model import bts, silog_loss
+    B, H, W, ds, md, feat = 2, 352, 1216, "kitti", 80.0, DN161
+    nf = 512
+    gen = torch.Generator().manual_seed(2025)
+    P = O.make_decoder_params(feat, nf, gen, randomize_bn=True)
+    feats = O.make_features(feat, B, H, W, gen)
+    focal = O.synth_focal(B, ds)
+    gt = O.synth_depth_gt(B, H, W, ds, gen).to(DEV)
+    mask = gt > 1.0
+
+    def objective(outs, loss):
+        return loss + sum((o * o).mean() for o in outs[:4])
+
+    def run_oracle(dt):
+        Pd = {k: ((v.to(DEV).to(dt)).requires_grad_(True) if v.dtype.is_floating_point and "running" not in k
+                  else (v.to(DEV).to(dt) if v.dtype.is_floating_point else v.to(DEV))) for k, v in P.items()}
+        fr = [f.to(DEV).to(dt).requires_grad_(True) for f in feats]
+        with torch.backends.cudnn.flags(enabled=False):
+            ref, _ = O.decoder_forward(Pd, fr, focal.to(DEV).to(dt), md, ds, True)
+            loss = O.silog(ref[4], gt.to(dt), mask, 0.85)
+            objective(ref, loss).backward()
+        g = {k: v.grad.detach() for k, v in Pd.items() if v.dtype.is_floating_point and v.requires_grad}
+        for i, f in enumerate(fr):
+            g["feat%d" % i] = f.grad.detach()
+        return [r.detach() for r in ref], g
+    o64, g64 = run_oracle(torch.float64)
+    o32, g32 = run_oracle(torch.float32)
+    dec = bts(NS(max_depth=md, dataset=ds, encoder="densenet161_bts", bts_size=nf, decoder_dtype=torch.float32), feat, nf)
+    dec.load_state_dict(P)
+    dec.to(DEV).train()
+    fs = [f.to(DEV).requires_grad_(True) for f in feats]
+    outs = dec(fs, focal.to(DEV))
+    loss = silog_loss(0.85)(outs[4], gt, mask)
+    objective(outs, loss).backward()
+    gp = {n: p.grad for n, p in dec.named_parameters()}
+    for i, f in enumerate(fs):
+        gp["feat%d" % i] = f.grad
+    for i in range(5):                       # outputs, element-wise against f64 (north_star's bound)
+        r = o64[i].double()
+        e = ((outs[i].double() - r).abs() / r.abs().clamp_min(1e-30)).max().item()
+        assert e < 1e-4, (i, e)
+    worst, bad = (None, 0.0, 0.0), {}
+    for k, g in g64.items():
+        ep, et = l2rel(gp[k], g), l2rel(g32[k], g)
+        if ep > worst[1]:
+            worst = (k, ep, et)
+        if not ep <= max(1e-4, 2.0 * et):
+            bad[k] = (ep, et)
+    print("f64-arbitrated gradients: worst product %.2e (torch f32 %.2e) at %s" % (worst[1], worst[2], worst[0]))
+    assert not bad, bad
+
+
 # BASELINE.json configs[4]: the bts_test.py path (bts_test.py:84-128: model.eval(), torch.no_grad(), five outputs) at 704x1216,
 # DenseNet161 widths.  The no-grad decoder runs the four LPG heads as fused chain kernels (reduction_1x1 + plane + LPG in one
 # launch, lpg_chain_fwd_kernel<., 128|64|32, ., 8|4|2|1>); the checker is the oracle's formulas in f32 on the device.  Batch 4
