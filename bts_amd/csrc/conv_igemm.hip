@@ -276,11 +276,21 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
             auto rd = [&](u32x4_t& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); };
             auto rdA = [&](int set, int i, int s) { rd(fa[set][i], sTa + offA[i] + (((2 * s + fk) ^ swz) << 4)); };
             auto rdB = [&](int set, int j, int s) { rd(fb[set][j], sTa + offB[j] + (((2 * s + fk) ^ swz) << 4)); };
+#ifdef BTS_ABL_NODMA      // diagnostic ablation (tools/build_trace_lib.sh): no staging at all -- MFMAs on whatever LDS holds, timing only
+            auto dmaA = [&](int) {};
+            auto dmaB = [&](int) {};
+            (void)sAw; (void)sBw;
+#else
             auto dmaA = [&](int i) { __builtin_amdgcn_global_load_lds((gptr_t)srcA[i], (lptr_t)(sAw + (wave * 8 + RP * i) * 128), 16, 0, 0); };
             auto dmaB = [&](int i) { __builtin_amdgcn_global_load_lds((gptr_t)srcB[i], (lptr_t)(sBw + (wave * 8 + RP * i) * 128), 16, 0, 0); };
+#endif
             auto mm = [&](int set, int i, int j) {
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef BTS_ABL_NOMFMA    // diagnostic ablation: staging and fragment reads only
                 Mma<T>::run(fa[set][i], fb[set][j], acc[i][j]);
+#else
+                asm volatile("" :: "v"(fa[set][i]), "v"(fb[set][j]));
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             };
             static_assert(RA == 4 && RB == 4, "8 DMA instructions per thread per chunk");

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bts_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "bts_amd", "lib", "libbts_amd_trace.so")
+_lib.LIB_PATH = os.environ.get("BTS_TRACE_LIB") or os.path.join(ROOT, "bts_amd", "lib", "libbts_amd_trace.so")
 from bts_amd._lib import ACT_ELU  # noqa: E402
 from bts_amd.conv import ConvLayer  # noqa: E402
 
@@ -59,7 +59,7 @@ def main():
         if rows:
             r = torch.tensor(rows, dtype=torch.float64)
             m = r.mean(0)
-            out.append(dict(case=name, waves=len(rows), chunks=int(m[5].item()),
+            out.append(dict(lib=os.path.basename(_lib.LIB_PATH), case=name, waves=len(rows), chunks=int(m[5].item()),
                             prep_and_vmcnt_wait=round(m[0].item()), barrier_wait=round(m[1].item()), reads_mfma_section=round(m[2].item()),
                             loop_tail=round(m[3].item()), chunk_total=round(m[4].item()),
                             mfma_issue_floor=512, note="shader-clock cycles (s_memtime), means over the steady-state chunks of the stamped waves"))
