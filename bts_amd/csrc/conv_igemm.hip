@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_igemm_dma(const ConvK a) {
             (void)sAw; (void)sBw;
 #else
             auto dmaA = [&](int i) { __builtin_amdgcn_global_load_lds((gptr_t)srcA[i], (lptr_t)(sAw + (wave * 8 + RP * i) * 128), 16, 0, 0); };
-            auto dmaB = [&](int i) { __builtin_amdgcn_global_load_lds((gptr_t)srcB[i], (lptr_t)(sBw + (wave * 8 + RP * i) * 128), 16, 0, 0); };
+            auto dmaB = [&](int i) { __builtin_amdgcn_global_load_lds((gptr_t)srcB[i], (lptr_t)(sBw + (wave * 8 + RP * i) * 128), 16, 0, 0); };   // (the nt policy -- aux = 2 -- on either operand: +12..27 %, gpurun r05o: both are re-read from L2)
 #endif
             auto mm = [&](int set, int i, int j) {
                 __builtin_amdgcn_sched_barrier(0);
