@@ -301,6 +301,19 @@ def _buffer_worker(rank, world, port, flatten, q):
         outs = [torch.zeros_like(ye) for _ in range(world)]
         dist.all_gather(outs, ye)
         assert all(torch.equal(outs[0], o) for o in outs), "eval outputs differ across ranks"
+        if flatten:
+            # Something re-binds a buffer after construction (module.to(dtype), load_state_dict(assign=True), register_buffer): the
+            # module no longer points at BufferSync's view, a broadcast of the flat tensor would sync nothing.  The sync must notice
+            # and fall back to gather / broadcast / scatter over the LIVE buffers (advisor item of round 4).
+            bn = [m for m in net.modules() if isinstance(m, nn.BatchNorm2d)][0]
+            assert sync._views_intact()
+            bn._buffers["running_mean"] = torch.full_like(bn.running_mean, 10.0 + rank)     # rank-dependent, outside the flat tensor
+            assert not sync._views_intact()
+            sync()
+            assert not sync.flattened
+            got = [torch.zeros_like(bn.running_mean) for _ in range(world)]
+            dist.all_gather(got, bn.running_mean)
+            assert all(torch.equal(g, torch.full_like(g, 10.0)) for g in got), "stale views: the re-bound buffer was not synchronised"
         q.put((rank, "ok"))
     except Exception as e:   # noqa: BLE001
         import traceback
