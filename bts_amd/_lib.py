@@ -49,6 +49,7 @@ class ConvDesc(C.Structure):
         ("fold_elu_y", C.c_void_p), ("fold_elu_stride", C.c_int32),
         ("w2", C.c_void_p), ("y2", C.c_void_p), ("Cout2", C.c_int32), ("y2_stride", C.c_int32), ("accumulate2", C.c_int32),
         ("w_frag", C.c_int32),
+        ("stats_ws", C.c_void_p),
     ]
 
 
@@ -108,6 +109,7 @@ SIGNATURES = {
     "bts_silog_fwd": [_p, _p, _p, _f, _l, _f, _p, _p, _p, _p],
     "bts_silog_bwd": [_p, _p, _p, _f, _l, _f, _p, _p, _p, _p, _p],
     "bts_conv_fwd": [C.POINTER(ConvDesc), _p],
+    "bts_conv_fwd_stats_rows": [C.POINTER(ConvDesc), C.POINTER(C.c_int)],
     "bts_conv_wgrad": [C.POINTER(ConvDesc), _p, _i, _p, _p],
     "bts_conv_wgrad_group": [_p, _p, _p, _p, _i, _p],
     "bts_conv3x3_c1_fwd": [_p, _i, _i, _i, _p, _p, _i, _i, _i, _f, _p, _p],
@@ -121,6 +123,7 @@ SIGNATURES = {
     "bts_nhwc_to_nchw": [_p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p],
     "bts_bn_stats_workspace_bytes": [_l, _i],
     "bts_bn_stats": [_p, _i, _i, _l, _i, _p, _p, _p, _p],
+    "bts_bn_stats_finalize": [_p, _i, _i, _l, _p, _p, _p],
     "bts_bn_prepare": [_p, _p, _i, _l, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p],
     "bts_affine_act": [_p, _i, _i, _p, _i, _i, _l, _i, _p, _p, _i, _p],
     "bts_bn_bwd_reduce": [_p, _i, _p, _i, _i, _l, _i, _p, _p, _p, _p, _i, _p, _p, _p],
@@ -153,7 +156,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.argtypes = args
         fn.restype = C.c_long if name in _LONG_RET else C.c_int
-    if lib.bts_abi_version() != 3:
+    if lib.bts_abi_version() != 4:
         raise BtsAmdError("libbts_amd.so ABI version mismatch")
     _lib = lib
     return lib

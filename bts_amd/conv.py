@@ -146,6 +146,7 @@ class ConvLayer:
             self.taps, self.masks = _taps_plain(kk, dil)
             self.nphase, self.T = 1, len(self.taps)
         self._cache = {}
+        self._stats_rows = {}      # launch shape -> rows of partial statistics the selected kernel writes (0: none)
 
     # -- per (dtype, device) tables ----------------------------------------------------------
     def tables(self, dtype, device):
@@ -264,9 +265,12 @@ class ConvLayer:
         d.Hx, d.Wx = segs[0].shape[1], segs[0].shape[2]
         return d
 
-    def forward(self, segs, wp, out, act, out_scale=1.0, out_scale_n=None, w_frag=0):
+    def forward(self, segs, wp, out, act, out_scale=1.0, out_scale_n=None, w_frag=0, stats=None):
         """segs: NHWC input tensors (padded channels); wp = pack_fwd(weight); out: NHWC [N,Ho,Wo,>=Cout]
-        or a single-channel f32 map [N,Ho,Wo].  w_frag: layout of wp (frag_layout())."""
+        or a single-channel f32 map [N,Ho,Wo].  w_frag: layout of wp (frag_layout()).
+        stats: a list; when the kernel this launch selects has the statistics epilogue (include/bts_amd.h:
+        bts_conv_desc_t::stats_ws), the batch statistics (mean, biased var) of `out` -- what ops.bn_stats(out) would compute with
+        one more pass over it -- are appended; left empty otherwise (the caller then runs ops.bn_stats when it needs them)."""
         dtype = segs[0].dtype
         N, Hx, Wx, _ = segs[0].shape
         d = self._desc(dtype, segs, N, Hx, Wx)
@@ -283,6 +287,17 @@ class ConvLayer:
         d.out_scale = out_scale
         d.out_scale_n = out_scale_n.data_ptr() if out_scale_n is not None else None
         d.accumulate = 0
+        ws = None
+        if stats is not None and out.dim() == 4 and out.dtype == torch.bfloat16:
+            key = (dtype, N, Hx, Wx, pix_stride(out), act, w_frag, out_scale, out_scale_n is None)
+            rows = self._stats_rows.get(key)
+            if rows is None:          # a property of the kernel the descriptor selects: asked once per launch shape
+                r = C.c_int(0)
+                rows = r.value if _lib.load().bts_conv_fwd_stats_rows(C.byref(d), C.byref(r)) == 0 else 0
+                self._stats_rows[key] = rows
+            if rows:
+                ws = torch.empty((rows, 2, self.cout), dtype=torch.float32, device=out.device)
+                d.stats_ws = ws.data_ptr()
         if profiler.ACTIVE is not None:
             M = N * Hx * Wx
             kv = sum(pad_to(c, vec_of(dtype)) for c in self.seg_channels) // vec_of(dtype)
@@ -291,6 +306,14 @@ class ConvLayer:
             profiler.note("conv_igemm_res<bf16,128xN>" if w_frag else _fwd_kernel(dtype, self.cout, self.kk == 9 and self.dil == 1, (N, Hx, Wx), kv, self.up), "mfma",
                           2.0 * M * self.nphase * self.T * self.cin * self.cout, self.name + ".fwd", nb)
         call("bts_conv_fwd", C.byref(d), stream_ptr())
+        if ws is not None:
+            Mo = out.shape[0] * out.shape[1] * out.shape[2]
+            mean = torch.empty(self.cout, dtype=torch.float32, device=out.device)
+            var = torch.empty(self.cout, dtype=torch.float32, device=out.device)
+            if profiler.ACTIVE is not None:
+                profiler.note("bn_stats_finalize", "hbm", ws.numel() * 4)
+            call("bts_bn_stats_finalize", ws.data_ptr(), ws.shape[0], self.cout, Mo, mean.data_ptr(), var.data_ptr(), stream_ptr())
+            stats.append((mean, var))
         return out
 
     @staticmethod

@@ -61,6 +61,7 @@ struct ConvK {
     int halo_ok;   // every tap within radius 1 on an unscaled same-size input: eligible for conv_halo
     int kmajor;    // conv_igemm_dma K order: 1 = channel chunk outer, taps inner (needs KV % 8 == 0); 0 = tap outer
     int wfrag;     // bts_conv_desc_t::w_frag: 0 = [Cout][taps][K] weights, 1 = MFMA A-fragment order (conv_igemm_res)
+    float* stats;  // bts_conv_desc_t::stats_ws: per-(phase, pixel tile, wave column) partial sums / sums of squares of the STORED output
 };
 
 // The strength-reduced address paths multiply (pixel index) x (pixel stride in bytes) in 32 bits: a launcher that uses them
@@ -363,12 +364,102 @@ __device__ __forceinline__ void store_block32_rmw_bf16(const ConvK& a, size_t op
     }
 }
 
+// Batch statistics of the output from the epilogue (bts_conv_desc_t::stats_ws; r5): the accumulator tile is in registers when the
+// convolution ends, so the BatchNorm that follows (bts.py:154-162, 200-208: bn5 / bn4 / bn3 behind the up-convolutions, the two
+// BatchNorms of every atrous_conv) needs no separate pass over the tensor for its mean / variance.  Per wave and 32-channel row tile:
+// the STORED values (activation applied, rounded to bf16 -- what a bn_stats pass over the tensor would read) of the wave's TN pixel
+// tiles are summed per register (channel), then a reduce-scatter butterfly over the 32 lanes (pixels) of each half-wave halves the
+// register set at every step (16 -> 8 -> 4 -> 2 -> 1 values per lane: 16 cross-lane exchanges per statistic instead of 80), and
+// lane pairs write 16 + 16 channel partials into row (phase, pixel tile, wave column) of ws[row][2][Cout].  Rows are summed in row
+// order by bn_stats_final_kernel (bts_bn_stats_finalize): deterministic, no atomics.
+// One step of the reduce-scatter: lanes whose bit `mask` is set keep the upper N registers, the others the lower N, each adds its
+// partner's other half.  N is a template parameter so that every register index is a constant (a run-time N -- the step loop
+// unrolled late -- became 1800 v_cndmask of dynamic register indexing: gpurun r05r, +20 us on a 40 us launch).
+template <int N>
+__device__ __forceinline__ void stats_rs_step(float (&s)[16], float (&q)[16], bool up, int mask) {
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        const float ks = up ? s[t + N] : s[t], ss = up ? s[t] : s[t + N];
+        const float kq = up ? q[t + N] : q[t], sq = up ? q[t] : q[t + N];
+        s[t] = ks + __shfl_xor(ss, mask, 64);
+        q[t] = kq + __shfl_xor(sq, mask, 64);
+    }
+}
+
+// The EPI 1 / 5 epilogue with statistics: same values, same stores as the plain form; the loops run row tile outermost so that one
+// row tile's 16 + 16 accumulators are live at a time, and the statistics are formed from the PACKED words the store writes.
+template <typename T, int WC, int TM, int TN, int EPI>
+__device__ __forceinline__ void epilogue_store_stats(const ConvK& a, f32x16_t (&acc)[TM][TN], int co_tile, int px_tile, int phase,
+                                                     int wr, int wc, int frow, int fk, int BM, int BN) {
+    size_t opix[TN];
+    bool ok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int m = px_tile * BN + (wc * TN + j) * 32 + frow;
+        ok[j] = m < a.M;
+        const uint32_t mm = ok[j] ? m : 0;
+        const uint32_t n = fdiv(mm, a.fd_hw);
+        const uint32_t rem = mm - n * (uint32_t)(a.Hg * a.Wg);
+        const uint32_t y = fdiv(rem, a.fd_w);
+        const uint32_t x = rem - y * a.Wg;
+        opix[j] = ((size_t)n * a.Hy + (y * a.osc + (phase >> 1))) * a.Wy + (x * a.osc + (phase & 1));
+    }
+    const size_t row = ((size_t)phase * a.n_px_tiles + px_tile) * WC + wc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int cb = co_tile * BM + (wr * TM + i) * 32;
+        if (cb >= a.Cout) continue;
+        float s[16], q[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = q[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (!ok[j]) continue;
+            uint32_t pk[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v0 = EPI == 1 ? act_elu_for<T>(acc[i][j][2 * e]) : acc[i][j][2 * e];
+                const float v1 = EPI == 1 ? act_elu_for<T>(acc[i][j][2 * e + 1]) : acc[i][j][2 * e + 1];
+                pk[e] = pack_bf16x2(v0, v1);                                                 // the stored (rounded) values
+                const float b0 = __uint_as_float(pk[e] << 16), b1 = __uint_as_float(pk[e] & 0xffff0000u);
+                s[2 * e] += b0; q[2 * e] += b0 * b0;
+                s[2 * e + 1] += b1; q[2 * e + 1] += b1 * b1;
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {                                                    // store_block32_plain_bf16's stores
+                const auto r0 = __builtin_amdgcn_permlane32_swap(pk[4 * p], pk[4 * p + 2], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(pk[4 * p + 1], pk[4 * p + 3], false, false);
+                *(u32x4_t*)((uint16_t*)a.y + opix[j] * a.y_stride + cb + 8 * (2 * p + fk)) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+            }
+        }
+        // reduce-scatter over lane bits 4, 3, 2, 1 (register count 16 -> 1), then a plain add over bit 0
+        stats_rs_step<8>(s, q, (frow & 16) != 0, 16);
+        stats_rs_step<4>(s, q, (frow & 8) != 0, 8);
+        stats_rs_step<2>(s, q, (frow & 4) != 0, 4);
+        stats_rs_step<1>(s, q, (frow & 2) != 0, 2);
+        const float ts = s[0] + __shfl_xor(s[0], 1, 64), tq = q[0] + __shfl_xor(q[0], 1, 64);
+        if ((frow & 1) == 0) {
+            // register index this lane ended up with: bit 3 <- lane bit 4, bit 2 <- lane bit 3, bit 1 <- lane bit 2, bit 0 <- lane bit 1
+            const int r = ((frow >> 4) & 1) << 3 | ((frow >> 3) & 1) << 2 | ((frow >> 2) & 1) << 1 | ((frow >> 1) & 1);
+            const int ch = cb + 8 * (r >> 2) + 4 * fk + (r & 3);
+            a.stats[(row * 2 + 0) * a.Cout + ch] = ts;
+            a.stats[(row * 2 + 1) * a.Cout + ch] = tq;
+        }
+    }
+}
+
 // EPI (launcher-checked; bf16, Cout % 32 == 0, aligned rows, out_scale == 1): 0 = generic, 1 = ELU + plain 16-byte stores,
 // 2 / 3 / 4 = no activation + read-modify-write (accumulate / ELU fold / both), 5 = no activation + plain 16-byte stores
 template <typename T, int WR, int WC, int TM, int TN, int EPI = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16_t (&acc)[TM][TN], int co_tile, int px_tile, int phase,
                                               int wr, int wc, int frow, int fk) {
     constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
+    if constexpr (EPI == 1 || EPI == 5) {
+        if (a.stats) {
+            epilogue_store_stats<T, WC, TM, TN, EPI>(a, acc, co_tile, px_tile, phase, wr, wc, frow, fk, BM, BN);
+            return;
+        }
+    }
     if constexpr (EPI != 0) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {

@@ -381,7 +381,7 @@ __device__ __forceinline__ void gload16(u32x4_t& d, const char* p) {
 constexpr int RES_MAX_CHUNKS = 4;
 
 template <int WR, int WC, int TM, int TN, int EPI>
-__global__ __launch_bounds__(64 * WR * WC) void conv_igemm_res(const ConvK a) {
+__global__ __launch_bounds__(64 * WR * WC, EPI == 0 ? 1 : 2) void conv_igemm_res(const ConvK a) {
     using T = BF16;
     constexpr int NW = WR * WC;
     constexpr int BM = WR * TM * 32, BN = WC * TN * 32;
@@ -578,16 +578,24 @@ static int epilogue_form(const ConvK& k, bool bf16, bool plain_none_too) {
     return 0;
 }
 
+// q_rows != nullptr: launch nothing; answer how many rows of partial batch statistics (bts_conv_desc_t::stats_ws) the launch this
+// descriptor selects would write -- 0 when the selected kernel has no statistics epilogue (bts_conv_fwd_stats_rows).
 template <typename T>
-static int launch_fwd(const ConvK& k0, hipStream_t st) {
+static int launch_fwd(const ConvK& k0, hipStream_t st, int* q_rows = nullptr) {
     ConvK k = k0;
-    auto go = [&](auto kern, int BM, int BN, int threads) {
+    const bool wants = k.stats != nullptr || q_rows != nullptr;
+    // a kernel without the statistics epilogue was selected: the query answers 0 rows, a launch that asked for them is refused
+    // before anything runs (the selection is never changed by the request: the convolution's own time comes first)
+    auto no_stats = [&]() { if (q_rows) { *q_rows = 0; return (int)BTS_OK; } return (int)BTS_ERR_UNSUPPORTED; };
+    auto go = [&](auto kern, int BM, int BN, int threads, int WC) {
         k.n_co_tiles = ceil_div(k.Cout, BM);
         k.n_px_tiles = ceil_div(k.M, BN);
+        if (q_rows) { *q_rows = k.nphase * k.n_px_tiles * WC; return; }
         dim3 grid(k.n_co_tiles * k.n_px_tiles, k.nphase);
         hipLaunchKernelGGL(kern, grid, dim3(threads), 0, st, k);
     };
     constexpr bool BF = T::kBytes == 2;
+    if (wants && !BF) return no_stats();
     if (k.wfrag) {
         // weights in A-fragment order: only conv_igemm_res reads that layout.  The caller decides by the static rule of
         // bts_amd/conv.py::frag_layout (bf16, more than 64 output rows, a launch no 2-D-tile kernel takes, <= 4 chunks of K).
@@ -598,12 +606,14 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
             const int nchunks = (k.T * k.KV + 7) >> 3;
             if (k.Cout <= 64 || k.wfrag != 1 || nchunks > RES_MAX_CHUNKS) return BTS_ERR_ARG;
             const int epi = epilogue_form(k, BF, true);
+            if (wants && epi != 1 && epi != 5) return no_stats();
             // 2 x 2 waves of 64 x 64 on a 128-pixel tile.  Measured against it (gpurun r05c / r05d, removed): 4 x 1 waves of 32 x 128
             // (263 vs 272 us over the eight launches: within the box spread, twice the fragment reads) and 64-pixel tiles with three
             // workgroups per CU (338 us: half the MACs per weight fragment loaded)
             auto go_res = [&](auto kern) {
                 k.n_co_tiles = ceil_div(k.Cout, 128);
                 k.n_px_tiles = ceil_div(k.M, 128);
+                if (q_rows) { *q_rows = k.nphase * k.n_px_tiles * 2; return; }
                 hipLaunchKernelGGL(kern, dim3(k.n_px_tiles, k.nphase), dim3(256), 0, st, k);
             };
             if (epi == 1) go_res(conv_igemm_res<2, 2, 2, 2, 1>);
@@ -618,13 +628,15 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
     }
     // 33..64 output channels over several channel chunks (conv2: 161 -> 64): the pipelined 64-co form of conv_halo_wide
     if (wide_mode() && BF && k.halo_ok && k.Cout > 32 && k.Cout <= 64 && k.nphase == 1 && k.T == 9 && k.KV > 8) {
+        if (wants) return no_stats();
         const int rc = launch_halo_wide(k, st, 0);
         if (rc != BTS_ERR_UNSUPPORTED) return rc;
     }
     // narrow radius-1 layers (and the sub-pixel up-convolutions) with <= 64 output channels: 2-D tile with LDS halo (conv_halo.hip)
-    if (k.halo_ok && k.Cout <= 64) return launch_halo(k, st, !BF);
+    if (k.halo_ok && k.Cout <= 64) return wants ? no_stats() : launch_halo(k, st, !BF);
     // wide radius-1 3x3 layers: 2-D pixel tile with halo + per-tap weight streaming (conv_halo_wide.hip)
     if (wide_mode() && BF && k.halo_ok && k.Cout > 64 && k.nphase == 1 && k.T == 9 && k.KV >= 8) {
+        if (wants) return no_stats();
         const int rc = launch_halo_wide(k, st, wide_mode() >= 2);
         if (rc != BTS_ERR_UNSUPPORTED) return rc;
     }
@@ -638,22 +650,23 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
     //       sources in tools/probes/legacy/.
     //   64 co x 128 px and 32 co x 256 px, 4 waves, for the narrow layers outside conv_halo's domain (1x1 chains, dilated).
     const int epi = epilogue_form(k, BF, true);
+    if (wants && epi != 1 && epi != 5) return no_stats();
     // (r4, gpurun r04f: the short-K launches -- dense-ASPP 1x1 / dilated 3x3, upconv3 / 4 -- on 128 co x 64 px tiles, 48 KiB = three
     // workgroups per CU and twice the tiles, are 5-50 % SLOWER than on 128 x 128: not taken)
     if (k.Cout > 64) {
         if constexpr (BF) {
-            if (epi == 1) go(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 1>, 128, 128, 256);
-            else if (epi == 2) go(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 2>, 128, 128, 256);
-            else if (epi == 3) go(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 3>, 128, 128, 256);
-            else if (epi == 4) go(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 4>, 128, 128, 256);
-            else if (epi == 5) go(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 5>, 128, 128, 256);
-            else go(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8>, 128, 128, 256);
+            if (epi == 1) go(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 1>, 128, 128, 256, 2);
+            else if (epi == 2) go(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 2>, 128, 128, 256, 2);
+            else if (epi == 3) go(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 3>, 128, 128, 256, 2);
+            else if (epi == 4) go(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 4>, 128, 128, 256, 2);
+            else if (epi == 5) go(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8, 5>, 128, 128, 256, 2);
+            else go(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8>, 128, 128, 256, 2);
         } else {
-            go(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8>, 128, 128, 256);
+            go(conv_igemm_dma<T, 2, 2, 2, 2, 2, 8>, 128, 128, 256, 2);
         }
     } else {
-#define BTS_NARROW_(E) do { if (k.Cout > 32) go(conv_igemm_dma<T, 1, 4, 2, 1, 2, 1, E>, 64, 128, 256);      \
-                            else go(conv_igemm_dma<T, 1, 4, 1, 2, 2, 1, E>, 32, 256, 256); } while (0)
+#define BTS_NARROW_(E) do { if (k.Cout > 32) go(conv_igemm_dma<T, 1, 4, 2, 1, 2, 1, E>, 64, 128, 256, 4);      \
+                            else go(conv_igemm_dma<T, 1, 4, 1, 2, 2, 1, E>, 32, 256, 256, 4); } while (0)
         if constexpr (BF) {
             if (epi == 1) BTS_NARROW_(1);
             else if (epi == 2) BTS_NARROW_(2);
@@ -666,13 +679,25 @@ static int launch_fwd(const ConvK& k0, hipStream_t st) {
         }
 #undef BTS_NARROW_
     }
+    if (q_rows) return BTS_OK;
     BTS_LAUNCH_CHECK();
     return BTS_OK;
 }
 
+static int conv_fwd_impl(const bts_conv_desc_t* d, bts_stream_t stream, int* q_rows);
+
 }  // namespace
 
-extern "C" int bts_conv_fwd(const bts_conv_desc_t* d, bts_stream_t stream) {
+extern "C" int bts_conv_fwd(const bts_conv_desc_t* d, bts_stream_t stream) { return conv_fwd_impl(d, stream, nullptr); }
+
+extern "C" int bts_conv_fwd_stats_rows(const bts_conv_desc_t* d, int* rows) {
+    BTS_CHECK_ARG(rows != nullptr);
+    *rows = 0;
+    return conv_fwd_impl(d, nullptr, rows);
+}
+
+namespace {
+static int conv_fwd_impl(const bts_conv_desc_t* d, bts_stream_t stream, int* q_rows) {
     ConvK k{};
     int rc = fill_common(d, k);
     if (rc != BTS_OK) return rc;
@@ -717,6 +742,12 @@ extern "C" int bts_conv_fwd(const bts_conv_desc_t* d, bts_stream_t stream) {
         k.y2_stride = d->y2_stride;
         k.accumulate2 = d->accumulate2;
     }
-    return d->dtype == BTS_F32 ? launch_fwd<F32>(k, (hipStream_t)stream) : launch_fwd<BF16>(k, (hipStream_t)stream);
+    if (d->stats_ws) {   // batch statistics of the stored output: a plain single-output launch (what a BatchNorm follows in bts.py)
+        BTS_CHECK_ARG(((uintptr_t)d->stats_ws & 3) == 0);
+        if (d->y2 || d->accumulate || d->fold_elu_y || d->y_stride != d->Cout) return BTS_ERR_UNSUPPORTED;
+        k.stats = (float*)d->stats_ws;
+    }
+    return d->dtype == BTS_F32 ? launch_fwd<F32>(k, (hipStream_t)stream, q_rows) : launch_fwd<BF16>(k, (hipStream_t)stream, q_rows);
 }
+}  // namespace
 

@@ -867,6 +867,47 @@ extern "C" int bts_bn_stats(const void* x, int dtype, int stride, long M, int C,
     return BTS_OK;
 }
 
+// bn_stats_final_kernel for the partial rows of a convolution epilogue (bts_bn_stats_finalize): one row per wave column of every pixel
+// tile -- 3344 rows for upconv3 at the KITTI bench shape, which the 32-channel blocks above (four of them for 128 channels) would walk
+// at load latency.  8 channels x 128 row lanes per block, so C / 8 blocks share the rows; the row lanes are combined by a fixed-order
+// LDS tree in double.
+__global__ __launch_bounds__(1024) void bn_stats_final_wide_kernel(const float* __restrict__ ws, int nparts, int C, double M,
+                                                                   float* __restrict__ mean, float* __restrict__ var) {
+    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    double a = 0, b = 0, a1 = 0, b1 = 0;
+    if (c < C) {
+        int k = pl;
+        for (; k + 128 < nparts; k += 256) {
+            a += ws[((size_t)k * 2 + 0) * C + c];            b += ws[((size_t)k * 2 + 1) * C + c];
+            a1 += ws[((size_t)(k + 128) * 2 + 0) * C + c];   b1 += ws[((size_t)(k + 128) * 2 + 1) * C + c];
+        }
+        if (k < nparts) { a += ws[((size_t)k * 2 + 0) * C + c]; b += ws[((size_t)k * 2 + 1) * C + c]; }
+        a += a1; b += b1;
+    }
+    __shared__ double sa[128][9], sb[128][9];
+    sa[pl][cl] = a; sb[pl][cl] = b;
+    __syncthreads();
+    for (int off = 64; off > 0; off >>= 1) {
+        if (pl < off) { sa[pl][cl] += sa[pl + off][cl]; sb[pl][cl] += sb[pl + off][cl]; }
+        __syncthreads();
+    }
+    if (pl == 0 && c < C) {
+        const double mu = sa[0][cl] / M;
+        double v = sb[0][cl] / M - mu * mu;
+        if (v < 0) v = 0;
+        mean[c] = (float)mu; var[c] = (float)v;
+    }
+}
+
+extern "C" int bts_bn_stats_finalize(const void* partials, int rows, int C, long M, float* mean, float* var, bts_stream_t stream) {
+    BTS_CHECK_ARG(partials && mean && var && rows > 0 && C > 0 && M > 0 && ((uintptr_t)partials & 3) == 0);
+    hipLaunchKernelGGL(bn_stats_final_wide_kernel, dim3(ceil_div(C, 8)), dim3(1024), 0, (hipStream_t)stream, (const float*)partials, rows, C,
+                       (double)M, mean, var);
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
 extern "C" int bts_bn_prepare(const float* mean, const float* var, int C, long M, const float* gamma, const float* beta,
                               float eps, float momentum, float* running_mean, float* running_var, float* invstd,
                               float* scale, float* shift, bts_stream_t stream) {

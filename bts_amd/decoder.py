@@ -12,6 +12,7 @@ statistics, LPG heads and the five outputs are f32.  torch.cat never happens: ev
 its concatenated input as a list of segments.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -24,6 +25,8 @@ from .ops import pad_to, vec_of
 
 KITTI_FOCAL_REF = 715.0873  # bts.py:264
 BN_MOMENTUM = 0.01          # bts.py:154 etc.
+# A/B switch of the measurement protocol (tools/final_protocol.sh): 0 = every BatchNorm's batch statistics from a bn_stats pass
+EPI_STATS = os.environ.get("BTS_EPI_STATS", "1") != "0"
 # fused recompute backward of the narrow LPG chains; the tests flip this module constant to train the chains layer by layer
 # (the layer-wise path is the checker of the fused one, tests/test_gpu_2_decoder.py)
 FUSED_CHAIN_BWD = True
@@ -246,7 +249,10 @@ class DecoderRun:
         self.feat_src.append((src if relu else None, f.shape[1], src.dtype))
         return a
 
-    def conv(self, name, segs, act, out_map=False, out_f32=False, out_scale=1.0, out_scale_n=None):
+    def conv(self, name, segs, act, out_map=False, out_f32=False, out_scale=1.0, out_scale_n=None, stats_for=None):
+        """stats_for: prefix of a BatchNorm that normalises this output (bts.py:57-62, 199-208, 231-232).  When that BatchNorm is in
+        training mode the convolution's epilogue also forms the output's batch statistics where its kernel can (ConvLayer.forward:
+        stats), so bn_cat() finds them on the activation and needs no pass of its own over the tensor."""
         L = self.plan.layers[name]
         wp = self.packs.fwd[name]
         if len({id(s) for s in segs}) != len(segs):       # the ELU-fold bookkeeping (one fold per Act) relies on it
@@ -261,8 +267,11 @@ class DecoderRun:
             odt = torch.float32 if out_f32 else self.dtype
             cp = pad_to(L.cout, vec_of(odt))
             out = (torch.zeros if cp != L.cout else torch.empty)((N, Ho, Wo, cp), dtype=odt, device=dev)
-        L.forward(x, wp, out, act, out_scale, out_scale_n, self.packs.fwd_frag[name])
+        st = [] if (stats_for is not None and EPI_STATS and self.bn_training[stats_for] and not out_map and not out_f32) else None
+        L.forward(x, wp, out, act, out_scale, out_scale_n, self.packs.fwd_frag[name], st)
         y = Act(out, act if (not out_map and not out_f32 and out_scale == 1.0 and out_scale_n is None) else ACT_NONE)
+        if st:
+            y.stats = st[0]
         folds = [self._use(s, s.t.dtype == self.dtype) for s in segs]
         if self.record:
             def bwd():
@@ -567,9 +576,10 @@ class DecoderRun:
     def atrous(self, d, x):
         """atrous_conv minus first_bn (bts.py:57-62): x is already BN'd/ReLU'd."""
         p = "daspp_%d.atrous_conv.aconv_sequence" % d
-        a = self.conv(p + ".1", [x], ACT_NONE)
+        a = self.conv(p + ".1", [x], ACT_NONE, stats_for=p + ".2")
         a = self.bn(a, p + ".2", 1e-5, relu=True)                 # default eps (bts.py:60)
-        return self.conv(p + ".4", [a], ACT_NONE)
+        nxt = {3: 6, 6: 12, 12: 18, 18: 24}.get(d)                # the next block's first_bn sees this output (bts.py:211-218)
+        return self.conv(p + ".4", [a], ACT_NONE, stats_for="daspp_%d.atrous_conv.first_bn" % nxt if nxt else None)
 
     # ---- schedule (bts.forward, bts.py:196-266) ------------------------------------------------
     def forward(self, features, focal):
@@ -579,10 +589,10 @@ class DecoderRun:
         H, W = 2 * H2, 2 * W2
         s0, s1, s2, s3 = (self.feature(f[i]) for i in range(4))
         dense = self.feature(f[4], relu=True)                               # :198
-        u5 = self.bn(self.conv("upconv5.conv", [dense], ACT_ELU), "bn5", 1.1e-5, x_act=ACT_ELU)      # :199-200
+        u5 = self.bn(self.conv("upconv5.conv", [dense], ACT_ELU, stats_for="bn5"), "bn5", 1.1e-5, x_act=ACT_ELU)      # :199-200
         i5 = self.conv("conv5.0", [u5, s3], ACT_ELU)                        # :201-202
-        u4 = self.bn(self.conv("upconv4.conv", [i5], ACT_ELU), "bn4", 1.1e-5, x_act=ACT_ELU)        # :204-205
-        i4, i4r = self.bn(self.conv("conv4.0", [u4, s2], ACT_ELU), "bn4_2", 1.1e-5, x_act=ACT_ELU, relu_copy=True)   # :206-208
+        u4 = self.bn(self.conv("upconv4.conv", [i5], ACT_ELU, stats_for="bn4"), "bn4", 1.1e-5, x_act=ACT_ELU)        # :204-205
+        i4, i4r = self.bn(self.conv("conv4.0", [u4, s2], ACT_ELU, stats_for="bn4_2"), "bn4_2", 1.1e-5, x_act=ACT_ELU, relu_copy=True)   # :206-208
         d3 = self.atrous(3, i4r)                                            # :210 (no first_bn; the ReLU of :58 comes with bn4_2)
         cat = [u4, s2, d3]
         dk = {3: d3}
@@ -593,10 +603,10 @@ class DecoderRun:
         df = self.conv("daspp_conv.0", [i4, dk[3], dk[6], dk[12], dk[18], dk[24]], ACT_ELU)   # :219-220
 
         d8 = self.lpg_branch("reduc8x8", df, 8)                             # :222-228
-        u3 = self.bn(self.conv("upconv3.conv", [df], ACT_ELU), "bn3", 1.1e-5, x_act=ACT_ELU)        # :231-232
+        u3 = self.bn(self.conv("upconv3.conv", [df], ACT_ELU, stats_for="bn3"), "bn3", 1.1e-5, x_act=ACT_ELU)        # :231-232
         i3 = self.conv("conv3.0", [u3, s1, self.slots([d8], [4], N, H // 4, W // 4)], ACT_ELU)   # :229, 233-234
         d4 = self.lpg_branch("reduc4x4", i3, 4)                             # :236-242
-        u2 = self.bn(self.conv("upconv2.conv", [i3], ACT_ELU), "bn2", 1.1e-5, x_act=ACT_ELU)        # :245-246
+        u2 = self.bn(self.conv("upconv2.conv", [i3], ACT_ELU, stats_for="bn2"), "bn2", 1.1e-5, x_act=ACT_ELU)        # :245-246
         i2 = self.conv("conv2.0", [u2, s0, self.slots([d4], [2], N, H // 2, W // 2)], ACT_ELU)   # :243, 247-248
         d2 = self.lpg_branch("reduc2x2", i2, 2)                             # :250-256
         u1 = self.conv("upconv1.conv", [i2], ACT_ELU)                       # :258

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BTS_AMD_ABI_VERSION 3
+#define BTS_AMD_ABI_VERSION 4
 
 enum { BTS_F32 = 0, BTS_BF16 = 1 };
 enum { BTS_ACT_NONE = 0, BTS_ACT_ELU = 1, BTS_ACT_SIGMOID = 2, BTS_ACT_RELU = 3 };
@@ -231,6 +231,17 @@ typedef struct {
      * rows >= Cout and flattened indices >= T * Ktot are zero.  Written by bts_pack_weight_batch (bts_pack_job_t::layout).
      * Domain: bf16, Cout > 64, T * Ktot <= 256 (four chunks), a launch the dispatcher sends to the implicit GEMM; BTS_ERR_ARG otherwise. */
     int32_t w_frag;
+    /* Batch statistics of the output from the convolution's own epilogue (round 5; optional: stats_ws != NULL).  The BatchNorms of
+     * bts.py:154-162 (atrous_conv: BN -> ReLU -> 1x1 conv -> BN -> ReLU -> dilated conv) and bts.py:200-208 (bn5 / bn4 / bn3 behind
+     * the up-convolutions) normalise with the batch statistics of a tensor a convolution has just written; the launch then also writes
+     * per-row-block partial sums of the STORED values (after the activation, rounded to y's dtype -- what bts_bn_stats reads):
+     *     stats_ws[row][0][c] = sum over the row block's pixels of y[.][c],   stats_ws[row][1][c] = sum of y[.][c]^2,
+     * float [rows][2][Cout], rows = bts_conv_fwd_stats_rows(d) (a property of the kernel the descriptor selects; every row is
+     * written, nothing needs clearing).  bts_bn_stats_finalize(stats_ws, rows, ...) turns them into mean / biased variance.
+     * Domain: bf16, single output (no y2 / accumulate / fold_elu_y), y_stride == Cout, Cout % 32 == 0, ELU or no activation, a launch
+     * the dispatcher sends to the implicit-GEMM kernels; outside it bts_conv_fwd_stats_rows answers 0 rows and a launch with stats_ws
+     * set answers BTS_ERR_UNSUPPORTED before anything runs (run the convolution without it, then bts_bn_stats). */
+    void* stats_ws;
 } bts_conv_desc_t;
 /* The descriptor MUST be zero-initialised before it is filled (`bts_conv_desc_t d = {0};` / memset): optional fields (fold_elu_y,
  * w2 / y2 / Cout2 / y2_stride / accumulate2, out_scale_n) are tested against NULL / 0, and fields added at the END of the struct
@@ -238,6 +249,9 @@ typedef struct {
  * check bts_abi_version() == the version of its header before passing the struct. */
 
 int bts_conv_fwd(const bts_conv_desc_t* d, bts_stream_t stream);
+/* Rows of partial statistics bts_conv_fwd(d) would write into d->stats_ws (the value of stats_ws itself is ignored); *rows = 0:
+ * the kernel this descriptor selects has no statistics epilogue.  Launches nothing. */
+int bts_conv_fwd_stats_rows(const bts_conv_desc_t* d, int* rows);
 
 /* 3x3 convolution (padding 1) to ONE output channel + sigmoid * scale, the `get_depth` layer (bts.py:193-194, 262-264), as a
  * streaming kernel (csrc/conv_c1.hip) instead of a 1-of-32-rows MFMA tile:
@@ -329,6 +343,9 @@ int bts_nhwc_to_nchw(const void* src, int src_dtype, int src_stride, void* dst, 
 long bts_bn_stats_workspace_bytes(long M, int C);
 int bts_bn_stats(const void* x, int dtype, int stride, long M, int C, void* workspace,
                  float* mean, float* var, bts_stream_t stream);
+/* mean[c], var[c] (biased) over M pixels from `rows` rows of partial sums [rows][2][C] (bts_conv_desc_t::stats_ws), summed in
+ * double in row order: the second half of bts_bn_stats for a tensor whose producing convolution already formed the partials. */
+int bts_bn_stats_finalize(const void* partials, int rows, int C, long M, float* mean, float* var, bts_stream_t stream);
 /* From (mean, var): invstd = 1/sqrt(var+eps), scale = gamma*invstd, shift = beta - mean*scale, and --
  * when running_mean/var are given -- the nn.BatchNorm2d running-stat update with `momentum` and the
  * unbiased variance (M/(M-1)).  Eval mode: pass the running stats as mean/var and NULL running_*.

@@ -61,7 +61,7 @@ def test_library_exports_all_symbols():
     lib = _lib.load()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.bts_abi_version() == 3
+    assert lib.bts_abi_version() == 4
     assert _lib.call("bts_silog_workspace_bytes", 1 << 20) > 0
 
 

@@ -516,6 +516,73 @@ def test_conv_epilogues():
     assert rel(m.unsqueeze(1), ref) < 1e-4
 
 
+STATS_CASES = [
+    # name, cout, seg_channels, kk, dil, up, (N,H,W), act is ELU, frag layout, rows expected (None: some, 0: no statistics epilogue)
+    ("up_elu_128", 128, [96], 9, 1, True, (2, 9, 13), True, False, None),          # conv_igemm_dma 128 x 128, ELU stores, four phases
+    ("up_elu_256_ragged", 256, [64, 72], 9, 1, True, (1, 11, 23), True, False, None),
+    ("up_elu_536rows", 128, [32], 9, 1, True, (2, 61, 70), True, False, None),      # 536 partial rows, ragged
+    ("c1x1_res", 256, [96, 64], 1, 1, False, (2, 17, 19), False, True, None),      # conv_igemm_res, ragged last pixel tile
+    ("c1x1_dma_longk", 128, [576], 1, 1, False, (2, 13, 21), False, False, None),  # 9 chunks: not the resident form
+    ("dil_64", 64, [128], 9, 12, False, (2, 21, 29), False, False, None),          # 64 x 128 tiles, four wave columns
+    ("dil_32", 32, [64], 9, 6, False, (1, 23, 31), False, False, None),            # 32 x 256 tiles
+    ("halo_no_stats", 64, [64], 9, 1, False, (2, 9, 13), True, False, 0),          # conv_halo: no statistics epilogue -> bn_stats
+    ("padded_no_stats", 72, [64], 1, 1, False, (2, 9, 13), False, False, 0),       # Cout % 32 != 0
+]
+
+
+@pytest.mark.parametrize("case", STATS_CASES, ids=[c[0] for c in STATS_CASES])
+def test_conv_epilogue_batch_statistics(case):
+    """bts_conv_desc_t::stats_ws: the batch statistics a convolution's epilogue forms of its own (stored, bf16) output are those of a
+    bn_stats pass over that output -- same values summed, only the f32 partial-sum grouping differs -- and the output itself is
+    bit-identical to the launch without them."""
+    from bts_amd.conv import ConvLayer
+    from bts_amd import ops
+    from bts_amd._lib import ACT_ELU, ACT_NONE
+    name, cout, segc, kk, dil, up, (N, H, W), elu, frag, rows_expected = case
+    dt = torch.bfloat16
+    gen = torch.Generator().manual_seed(sum(map(ord, name)))
+    cin = sum(segc)
+    xs = [torch.randn(N, c, H, W, generator=gen) + 0.3 for c in segc]       # non-zero channel means
+    k = 3 if kk == 9 else 1
+    w = torch.randn(cout, cin, k, k, generator=gen) * (1.0 / (cin * kk) ** 0.5)
+    L = ConvLayer(name, cout, segc, kk, dil, up)
+    segs = [_nhwc(x, dt, 8) for x in xs]
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    cp = (cout + 7) // 8 * 8
+    act = ACT_ELU if elu else ACT_NONE
+    wp, lay = L.pack_fwd(w.to(DEV), dt), 0
+    if frag:
+        lay = L.frag_layout(dt, cout, L.tables(dt, torch.device(DEV))["ktot"])
+        assert lay
+        wp = L.to_frag(wp, L._launch_taps(False)[0])
+    o0 = torch.zeros(N, Ho, Wo, cp, dtype=dt, device=DEV)
+    o1 = torch.zeros_like(o0)
+    L.forward(segs, wp, o0, act, w_frag=lay)
+    st = []
+    L.forward(segs, wp, o1, act, w_frag=lay, stats=st)
+    torch.cuda.synchronize()
+    assert torch.equal(o0, o1)
+    if rows_expected == 0:
+        assert st == [] and list(L._stats_rows.values()) == [0]
+        return
+    assert len(st) == 1 and all(r > 0 for r in L._stats_rows.values())
+    mean, var = st[0]
+    m_ref, v_ref = ops.bn_stats(o1)
+    xf = o1.double()
+    m64 = xf.mean((0, 1, 2))
+    v64 = xf.var((0, 1, 2), unbiased=False)
+    e2 = (xf * xf).mean((0, 1, 2))
+    # f32 partial sums over <= 256 values, combined in double: the mean to 1e-6 of the rms, the variance (E[x^2] - mean^2) likewise
+    em = ((mean.double() - m64).abs() / e2.sqrt()).max().item()
+    ev = ((var.double() - v64).abs() / e2).max().item()
+    em_ref = ((m_ref.double() - m64).abs() / e2.sqrt()).max().item()
+    ev_ref = ((v_ref.double() - v64).abs() / e2).max().item()
+    print("%s epilogue stats vs f64: mean %.2e var %.2e (bn_stats pass: %.2e %.2e), rows %s" % (name, em, ev, em_ref, ev_ref,
+                                                                                             list(L._stats_rows.values())))
+    _plog("conv_epilogue_stats", c0=cout, k=kk, dt=str(dt), name=name, l2=ev, max=em)
+    assert em < 2e-6 and ev < 2e-6
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("relu", [False, True])

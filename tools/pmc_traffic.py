@@ -57,6 +57,8 @@ def family(name):
         return "bn_bwd"
     if n.startswith("bn_apply_ms"):
         return "bn_apply"
+    if n.startswith("bn_stats_final_wide"):
+        return "bn_stats_finalize"
     if n.startswith("bn_stats_"):
         return "bn_stats"
     if n.startswith("conv_halo<BF16"):
