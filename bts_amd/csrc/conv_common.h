@@ -371,7 +371,8 @@ __device__ __forceinline__ void store_block32_rmw_bf16(const ConvK& a, size_t op
 // tiles are summed per register (channel), then a reduce-scatter butterfly over the 32 lanes (pixels) of each half-wave halves the
 // register set at every step (16 -> 8 -> 4 -> 2 -> 1 values per lane: 16 cross-lane exchanges per statistic instead of 80), and
 // lane pairs write 16 + 16 channel partials into row (phase, pixel tile, wave column) of ws[row][2][Cout].  Rows are summed in row
-// order by bn_stats_final_kernel (bts_bn_stats_finalize): deterministic, no atomics.
+// order by bn_stats_final_wide_kernel (bts_bn_stats_finalize): deterministic, no atomics.
+//
 // One step of the reduce-scatter: lanes whose bit `mask` is set keep the upper N registers, the others the lower N, each adds its
 // partner's other half.  N is a template parameter so that every register index is a constant (a run-time N -- the step loop
 // unrolled late -- became 1800 v_cndmask of dynamic register indexing: gpurun r05r, +20 us on a 40 us launch).
