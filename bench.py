@@ -90,7 +90,7 @@ def spawn_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL / cross-process tensors need it on this host driver
     env.setdefault("OMP_NUM_THREADS", "8")
-    return subprocess.call(cmd, env=env)
+    return subprocess.call(cmd, env=env, stdout=_RESULT_FD)      # the ranks' stdout is the REAL stdout (own_stdout() moved fd 1 to stderr)
 
 
 def set_misc(model):
@@ -507,7 +507,7 @@ def infer_main(args):
         out["absrel_vs_cpu_oracle"] = round(((est - ref_depth).abs() / ref_depth).mean().item(), 6)
         out["cpu_baseline"] = {"value": round(1.0 / cpu_s, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                                "sample": "oracle encoder+decoder forward, f32, 1 image %dx%d (%.1f s)" % (H, W, cpu_s)}
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 def plumbing_main(args, world, rank):
@@ -520,14 +520,43 @@ def plumbing_main(args, world, rank):
     el = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print(json.dumps({"plumbing": True, "n_gpus": world, "sum_ranks": t.item(), "max_elapsed": el.item(), "backend": args.backend}), flush=True)
+        emit({"plumbing": True, "n_gpus": world, "sum_ranks": t.item(), "max_elapsed": el.item(), "backend": args.backend})
     dist.destroy_process_group()
+
+
+_RESULT_FD = None
+
+
+def own_stdout():
+    """The contract is ONE line on stdout.  Libraries under this process write there too -- RCCL 2.26 prints a five-line version
+    banner (`RCCL version : ...`, `Librccl path : ...`) through C stdio when its first communicator comes up, which lands AFTER
+    the JSON line when stdout is a file or a pipe (seen on the world-1 RCCL run, profiles/r05_bench_world1_rccl.json.err) and MIOpen
+    can do the same.  So: keep a private copy of the real stdout for the result line and point fd 1 (C stdio and Python's
+    sys.stdout alike) at stderr for the rest of the process."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    """The result line, on the real stdout (own_stdout())."""
+    line = (json.dumps(obj) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+        return
+    while line:
+        n = os.write(_RESULT_FD, line)
+        line = line[n:]
 
 
 def main():
     args = parse()
+    own_stdout()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args)), flush=True)
+        emit(cpu_baseline(args))
         return
     if args.mode == "infer":
         return infer_main(args)
@@ -817,7 +846,7 @@ def main():
                 out["roofline_lpg_op"] = {"error": str(e)[:160]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 

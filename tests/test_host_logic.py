@@ -217,14 +217,28 @@ def test_bench_gpus_n_spawns_its_own_ranks():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--plumbing-only", "1"],
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    j = json.loads(line)
+    assert len(out.stdout.splitlines()) == 1, out.stdout          # ONE line on stdout, whatever the libraries underneath print
+    j = json.loads(out.stdout)
     assert j["n_gpus"] == 2 and j["sum_ranks"] == 3.0 and abs(j["max_elapsed"] - 0.002) < 1e-12
     # a launcher world that disagrees with --gpus: refuse rather than print a line with the wrong n_gpus
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--plumbing-only", "1"],
                          capture_output=True, text=True, timeout=120, env=env2)
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
+def test_bench_result_line_is_alone_on_stdout():
+    """bench.py's contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio (it lands after the line when
+    stdout is a pipe); own_stdout() keeps a private copy of stdout for the line and points fd 1 at stderr for everything else."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; bench.own_stdout(); "
+            "os.write(1, b'RCCL version : x\\n'); print('python-level noise'); bench.emit({'a': 1}); os.write(1, b'late noise\\n')" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout == json.dumps({"a": 1}) + "\n"
+    assert "RCCL version" in out.stderr and "python-level noise" in out.stderr and "late noise" in out.stderr
 
 
 def test_build_manifest_matches_sources():
