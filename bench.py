@@ -22,12 +22,50 @@ import sys
 import time
 from types import SimpleNamespace as NS
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+def _flag(name, default):
+    """Value of `--name V` / `--name=V` on the command line (read BEFORE argparse and before torch is imported: the MIOpen / ATen
+    switches below are environment variables the libraries read once, at their first convolution)."""
+    for i, a in enumerate(sys.argv):
+        if a == name and i + 1 < len(sys.argv):
+            return sys.argv[i + 1]
+        if a.startswith(name + "="):
+            return a.split("=", 1)[1]
+    return default
+
+
+def encoder_environment():
+    """How the STOCK encoder is run (`profiles/r06_ab_encoder_layout.json`: same-box A/B).  The encoder stays
+    PyTorch-ROCm / MIOpen; what is chosen here is its configuration:
+      * torch.channels_last tensors AND PYTORCH_MIOPEN_SUGGEST_NHWC(+_BATCHNORM)=1, so that ATen hands MIOpen the NHWC tensors as
+        they are (without the switch it makes NCHW copies, and MIOpen's NHWC kernels transpose around themselves:
+        batched_transpose_* was 13 % of the step);
+      * MIOpen's find results for exactly these layer shapes, recorded once on an MI355X by `tools/miopen_warm.sh` and shipped in
+        bts_amd/miopen_db/ (MIOPEN_USER_DB_PATH): this image has no gfx950 find-db, so without it every convolution runs the
+        solver an untuned heuristic picks.  MIOPEN_FIND_MODE=FAST: a shape that is in the db uses its recorded best solver, a
+        shape that is not falls back to the heuristic -- never a minutes-long search inside a benchmark run."""
+    nhwc = _flag("--miopen-nhwc", "1")
+    if nhwc in ("0", "1"):
+        os.environ["PYTORCH_MIOPEN_SUGGEST_NHWC"] = nhwc
+        os.environ["PYTORCH_MIOPEN_SUGGEST_NHWC_BATCHNORM"] = nhwc
+    db = _flag("--miopen-db", os.path.join(ROOT, "bts_amd", "miopen_db"))
+    if db and db != "none":
+        os.makedirs(db, exist_ok=True)
+        os.environ["MIOPEN_USER_DB_PATH"] = db
+    mode = _flag("--miopen-find-mode", "fast")
+    if mode != "default":
+        os.environ["MIOPEN_FIND_MODE"] = {"normal": "1", "fast": "2", "hybrid": "3", "dynamic_hybrid": "5"}[mode]
+
+
+if __name__ == "__main__" or os.environ.get("BTS_BENCH_ENV") == "1":
+    encoder_environment()
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 PEAK = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0
@@ -35,7 +73,7 @@ HBM_PEAK_GBS = 8000.0
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="default: WORLD_SIZE under a launcher, else 1")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
@@ -46,10 +84,20 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--channels-last", type=int, default=0)
+    ap.add_argument("--channels-last", type=int, default=1, help="run the stock encoder in torch.channels_last (model + input); the decoder "
+                    "then takes the features as NHWC views, no layout conversion either way (default since round 6: +5 %% alone, +17 %% with "
+                    "the recorded find results, profiles/r06_ab_encoder_layout.json)")
+    ap.add_argument("--miopen-nhwc", type=int, default=1, help="1 / 0: export PYTORCH_MIOPEN_SUGGEST_NHWC(+_BATCHNORM) = 1 / 0 before the first "
+                    "convolution (without it PyTorch-ROCm hands MIOpen NCHW copies of channels-last tensors); -1: leave the environment alone")
+    ap.add_argument("--miopen-db", default=os.path.join(ROOT, "bts_amd", "miopen_db"), help="MIOPEN_USER_DB_PATH: directory of the recorded "
+                    "MIOpen find results (tools/miopen_warm.sh writes it); 'none' = MIOpen's own default")
+    ap.add_argument("--miopen-find-mode", default="fast", choices=["fast", "normal", "hybrid", "dynamic_hybrid", "default"],
+                    help="MIOPEN_FIND_MODE: fast = recorded result or heuristic, never a search [default]; normal = full search, "
+                         "records into --miopen-db (what tools/miopen_warm.sh uses)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--graph", type=int, default=1, help="capture the train step in a hipGraph (N=1 only; falls back to eager)")
-    ap.add_argument("--cudnn-benchmark", type=int, default=0)
+    ap.add_argument("--cudnn-benchmark", type=int, default=1, help="torch.backends.cudnn.benchmark: ATen asks MIOpen's find API (which, in "
+                    "find mode `fast`, answers from the recorded results) instead of its immediate-mode heuristic")
     ap.add_argument("--optimizer", default="bts", choices=["bts", "torch"], help="bts = fused HIP AdamW (bts_adamw_step)")
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="infer = BASELINE.json configs[4]: no-grad forward, DenseNet161 704x1216 batch 32 (secondary config)")
@@ -77,16 +125,14 @@ def spawn_ranks(args):
     reference does (bts_main.py:600-602, `mp.spawn(main_worker, nprocs=ngpus_per_node)`) -- here by re-executing this script under
     `torch.distributed.run` (same command line), so the plain command the driver uses for N = 1 works verbatim for N = 8.  Rendezvous
     on 127.0.0.1 (the container hostname may not resolve).  Returns the launcher's exit code."""
-    import socket
     import subprocess
-    port = args.master_port
-    if not port:
-        sk = socket.socket()
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-        sk.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus)]
+    if args.master_port:
+        cmd += ["--master-addr", "127.0.0.1", "--master-port", str(args.master_port)]
+    else:
+        # no probe-then-close of a "free" port (a race on busy hosts): the launcher binds port 0 itself and tells its workers
+        cmd += ["--standalone", "--local-addr", "127.0.0.1"]
+    cmd += [os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL / cross-process tensors need it on this host driver
     env.setdefault("OMP_NUM_THREADS", "8")
@@ -193,7 +239,9 @@ def f32_line_subprocess(args, parity, timeout_s=240):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "f32", "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
            "--parity", "0", "--lpg-op", "0", "--f32-line", "0", "--eager-steps", "0", "--encoder", args.encoder, "--dataset", args.dataset,
-           "--height", str(args.height), "--width", str(args.width), "--batch", str(args.batch)]
+           "--height", str(args.height), "--width", str(args.width), "--batch", str(args.batch),
+           "--channels-last", str(args.channels_last), "--miopen-nhwc", str(args.miopen_nhwc), "--miopen-db", args.miopen_db,
+           "--miopen-find-mode", args.miopen_find_mode, "--cudnn-benchmark", str(args.cudnn_benchmark)]
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
         for line in reversed(res.stdout.strip().splitlines()):
@@ -208,6 +256,27 @@ def f32_line_subprocess(args, parity, timeout_s=240):
         return {"value": None, "error": res.stderr[-300:]}
     except subprocess.TimeoutExpired:
         return {"value": None, "error": "f32 child exceeded %d s" % timeout_s}
+
+
+def miopen_db_note(args):
+    """What the run found in --miopen-db BEFORE it started (a run in find mode `normal` adds to it)."""
+    return _DB_NOTE or "no recorded find results"
+
+
+_DB_NOTE = ""
+
+
+def scan_miopen_db(path):
+    global _DB_NOTE
+    try:
+        files = [f for f in os.listdir(path) if f.endswith(".ufdb.txt")]
+        n = 0
+        for f in files:
+            with open(os.path.join(path, f)) as fh:
+                n += sum(1 for ln in fh if ln.strip())
+        _DB_NOTE = "recorded find results: %d problems in %s" % (n, os.path.relpath(path, ROOT)) if files else ""
+    except OSError:
+        _DB_NOTE = ""
 
 
 def library_md5():
@@ -347,6 +416,32 @@ def parity_arbiter_f64(args, O, bts, P, feats, focal, md, dev, elem):
     res["bound"] = 1e-4
     res["met"] = bool(res["product_elem_max"] <= 1e-4)
     del dec
+    # bf16 attribution (same image, same arbiter): the product's bf16 decoder beside STOCK PyTorch's bf16 evaluation of the same
+    # formulas (the oracle's decoder_forward under torch.autocast(bfloat16) on the device: convolutions and the elementwise ops
+    # behind them in bf16).  A product error of the size torch's own bf16 evaluation shows is the precision of the format on these
+    # formulas, not the kernels; bar: product <= 1.5 x torch-bf16 at the 99.9th percentile and at the maximum.
+    try:
+        decb = bts(NS(max_depth=md, dataset=args.dataset, encoder=args.encoder, bts_size=512, decoder_dtype=torch.bfloat16),
+                   [f.shape[1] for f in f1], 512).to(dev)
+        decb.load_state_dict(P)
+        decb.train()
+        gotb = decb([f.clone() for f in f1], fo)
+        with torch.backends.cudnn.flags(enabled=False), torch.autocast("cuda", dtype=torch.bfloat16):
+            refb, _ = O.decoder_forward({k: v.clone() for k, v in P.items()}, [f.clone() for f in f1], fo, md, args.dataset, True)
+        refb = [r.float() for r in refb]
+        a = {"product_bf16_elem_max": float("%.3g" % max(elem(g, r, 1.0) for g, r in zip(gotb, ref64))),
+             "product_bf16_elem_p999": float("%.3g" % max(elem(g, r, 0.999) for g, r in zip(gotb, ref64))),
+             "torch_bf16_elem_max": float("%.3g" % max(elem(g, r, 1.0) for g, r in zip(refb, ref64))),
+             "torch_bf16_elem_p999": float("%.3g" % max(elem(g, r, 0.999) for g, r in zip(refb, ref64))),
+             "per_output_product_bf16_elem_p999": [float("%.3g" % elem(g, r, 0.999)) for g, r in zip(gotb, ref64)],
+             "per_output_torch_bf16_elem_p999": [float("%.3g" % elem(g, r, 0.999)) for g, r in zip(refb, ref64)],
+             "leg": "oracle formulas under torch.autocast('cuda', torch.bfloat16) on the device, same image / features / parameters"}
+        a["met"] = bool(a["product_bf16_elem_max"] <= 1.5 * a["torch_bf16_elem_max"] and
+                        a["product_bf16_elem_p999"] <= 1.5 * a["torch_bf16_elem_p999"])
+        res["bf16_attribution"] = a
+        del decb
+    except Exception as e:   # noqa: BLE001
+        res["bf16_attribution"] = {"error": str(e)[:200]}
     return res
 
 
@@ -441,13 +536,17 @@ def lpg_op_roofline(B, H, W, replays=5):
     del eqs, gs, outs, geqs
     torch.cuda.empty_cache()
     ach = mb / ms / 1e9
-    return {"kernel": "lpg_multi_kernel (bare LPG operator, k = 8, 4, 2 of one batch in one launch: bts_lpg_fwd_multi / bts_lpg_bwd_multi)",
-            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-            "alg_bytes_per_launch": round(mb / 2), "shape": "%dx%dx%d" % (B, H, W), "hbm_resident": True,
-            "timing": "hipGraph replay of the buffer rotation (device time incl. inter-kernel gaps)", "per_launch": mres,
-            "single_scale_launches": {"kernel": "lpg_fwd/bwd_kernel<k=8,4,2>: the same six problems as six launches (TF-op boundary as is)",
-                                      "achieved": round(single, 1), "frac": round(single / HBM_PEAK_GBS, 4),
-                                      "alg_bytes_per_launch": round(tot_b / 6), "per_kernel": res}}
+    # Headline = the SINGLE-SCALE launches: that is the reference's op boundary (local_planar_guidance.h:22-49) and the only form a
+    # decoder can issue -- depth_8x8 feeds conv3, whose output feeds reduc4x4, and so on (bts.py:229-256), so the three scales of one
+    # batch are never available together.  The one-launch form is a library entry point for callers that do hold them; secondary.
+    return {"kernel": "lpg_fwd/bwd_kernel<k=8,4,2> (bare LPG operator at the reference's op boundary: six single-scale launches, bts_lpg_fwd / bts_lpg_bwd)",
+            "bound": "hbm", "achieved": round(single, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(single / HBM_PEAK_GBS, 4), "traffic": None,
+            "alg_bytes_per_launch": round(tot_b / 6), "shape": "%dx%dx%d" % (B, H, W), "hbm_resident": True,
+            "timing": "hipGraph replay of the buffer rotation (device time incl. inter-kernel gaps)", "per_kernel": res,
+            "multi_scale_launch": {"kernel": "lpg_multi_kernel: k = 8, 4, 2 of one batch as ONE launch per direction (bts_lpg_fwd_multi / "
+                                             "bts_lpg_bwd_multi) -- not a launch the decoder issues, its scales depend on each other",
+                                   "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                                   "alg_bytes_per_launch": round(mb / 2), "per_launch": mres}}
 
 
 def infer_main(args):
@@ -482,6 +581,10 @@ def infer_main(args):
         ref_depth = ref[4]
     model.to(dev)
     image_d, focal_d = image.to(dev), focal.to(dev)
+    torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
+    if args.channels_last:
+        model.encoder.to(memory_format=torch.channels_last)
+        image_d = image_d.contiguous(memory_format=torch.channels_last)
 
     def step():
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
@@ -498,10 +601,43 @@ def infer_main(args):
     out = {"metric": "images/sec (inference forward) DenseNet161-BTS 704x1216", "value": round(B * args.steps / elapsed, 3),
            "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-           "config": {"workload": "%s no-grad forward, %dx%d, batch %d (BASELINE.json configs[4])" % (args.encoder, H, W, B)}}
+           "config": {"workload": "%s no-grad forward, %dx%d, batch %d (BASELINE.json configs[4])" % (args.encoder, H, W, B),
+                      "encoder": "stock PyTorch-ROCm (%s, PYTORCH_MIOPEN_SUGGEST_NHWC=%s, cudnn.benchmark=%d, MIOPEN_FIND_MODE=%s, %s)" % (
+                          "channels_last" if args.channels_last else "contiguous NCHW", os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC", "unset"),
+                          args.cudnn_benchmark, os.environ.get("MIOPEN_FIND_MODE", "unset"), miopen_db_note(args))}}
     if prof is not None:
         profiler.disable()
         out.update(prof.summary(PEAK[args.dtype], HBM_PEAK_GBS, args.steps))
+    # The output path behind the forward (bts_test.py:119-124, 179-185), timed on the last batch, 3 repeats:
+    #   reference style: per image, five f32 maps to the host (`.cpu().numpy().squeeze()`), then depth * 256 -> uint16 in numpy
+    #   device path    : bts_depth_to_u16 on the batch + ONE device -> host copy of 2 bytes per pixel (bts_amd/loops.py)
+    from bts_amd import evalops
+    import numpy as np
+
+    def ref_style():
+        res = []
+        for i in range(B):
+            maps = [o[i].float().cpu().numpy().squeeze() for o in outs]
+            res.append((maps[4] * 256.0).astype(np.uint16))
+        return res
+
+    def dev_style():
+        return evalops.depth_to_uint16(outs[4].float(), "kitti").cpu().numpy()
+    tt = {}
+    for name, fn in (("reference_style_five_f32_maps_per_image", ref_style), ("device_uint16_one_copy_per_batch", dev_style)):
+        fn()
+        torch.cuda.synchronize()
+        t1 = time.time()
+        for _ in range(3):
+            got = fn()
+        torch.cuda.synchronize()
+        tt[name] = round((time.time() - t1) / 3 * 1e3, 3)
+    a, b = ref_style(), dev_style()
+    fwd_ms = elapsed / args.steps * 1e3
+    out["output_path_ms"] = dict(tt, payload_identical=bool(all(np.array_equal(a[i], b[i, 0]) for i in range(B))),
+                                 images_per_s_with_reference_style_output=round(B / (fwd_ms + tt["reference_style_five_f32_maps_per_image"]) * 1e3, 2),
+                                 images_per_s_with_device_output=round(B / (fwd_ms + tt["device_uint16_one_copy_per_batch"]) * 1e3, 2),
+                                 note="per batch of %d; `value` is the forward alone (outputs stay on the device)" % B)
     if ref_depth is not None:
         est = outs[4][:1].float().cpu()
         out["absrel_vs_cpu_oracle"] = round(((est - ref_depth).abs() / ref_depth).mean().item(), 6)
@@ -555,11 +691,15 @@ def emit(obj):
 def main():
     args = parse()
     own_stdout()
+    if args.miopen_db != "none":
+        scan_miopen_db(args.miopen_db)
     if args.cpu_baseline_only:
         emit(cpu_baseline(args))
         return
     if args.mode == "infer":
         return infer_main(args)
+    if args.gpus is None:                         # left at its default: a launcher's world is adopted, an explicit mismatch refused
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))               # no launcher around us: become one (one rank per GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -572,6 +712,9 @@ def main():
     if args.plumbing_only:
         return plumbing_main(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if args.channels_last and os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC") != "1":
+        sys.exit("bench.py: --channels-last 1 needs --miopen-nhwc 1 (ATen would hand MIOpen NCHW copies and return NCHW-laid-out "
+                 "weight gradients for channels-last weights)")
     local = local % torch.cuda.device_count()      # (plumbing tests run several ranks on one GPU over gloo)
     torch.cuda.set_device(local)                   # before the process group: RCCL binds the communicator to the current device
     if world > 1:
@@ -750,6 +893,11 @@ def main():
 
     for _ in range(2):
         step()
+    if reducer is not None:
+        torch.cuda.synchronize()
+        reducer.zero_grad()
+        reducer.fraction_log, reducer._exposed = [], []
+        reducer.timing = True          # exposed_comm_ms / bucket_launch_fraction of the TIMED steps (two events per step, no sync)
     prof = None
     if not args.no_kernel_events and rank == 0 and graph is None and world == 1:
         prof = profiler.enable()      # N > 1: never inside the timed region (per-launch events on one rank would hold back all of them)
@@ -768,6 +916,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss.item())
+    exchange = None
+    if reducer is not None:
+        exchange = reducer.exchange_stats()
+        reducer.timing = False
+        exchange["note"] = ("exposed_comm_ms = device time between the last kernel of backward and the end of the waits for the bucket "
+                            "all-reduces (what the exchange adds to the step); bucket_launch_fraction[i] = share of the step's gradient "
+                            "hooks that had fired when bucket i went on the wire (buckets in launch order: decoder first; 1.0 = nothing "
+                            "left to overlap with); plus one un-overlapped buffer broadcast before every forward (DDP broadcast_buffers)")
     eager = None
     if world == 1 and graph is not None and args.eager_steps > 0:
         # the same step issued launch by launch from Python (no graph, no per-launch events): what `--gpus N` (N > 1) runs
@@ -823,7 +979,9 @@ def main():
                        (args.encoder, args.height, args.width, args.batch,
                         "kitti focal scaling" if args.dataset == "kitti" else "nyu (no focal scaling)"),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "grad_exchange": ("none" if not multi else ("torch DDP over %s" % args.backend if reducer is None else "bts GradAllReducer over %s" % args.backend)),
-                       "encoder": "stock PyTorch-ROCm (%s autocast)" % args.dtype, "decoder": "HIP kernels via libbts_amd.so", "launch": graph_note, "optimizer": "bts_adamw_step (fused HIP)" if own_opt else "torch.optim.AdamW(fused)",
+                       "encoder": "stock PyTorch-ROCm (%s autocast, %s, PYTORCH_MIOPEN_SUGGEST_NHWC=%s, cudnn.benchmark=%d, MIOPEN_FIND_MODE=%s, %s)" % (
+                           args.dtype, "channels_last" if args.channels_last else "contiguous NCHW", os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC", "unset"),
+                           args.cudnn_benchmark, os.environ.get("MIOPEN_FIND_MODE", "unset"), miopen_db_note(args)), "decoder": "HIP kernels via libbts_amd.so", "launch": graph_note, "optimizer": "bts_adamw_step (fused HIP)" if own_opt else "torch.optim.AdamW(fused)",
                        "final_loss": round(final_loss, 5)},
         }
         if roof is not None:
@@ -832,9 +990,21 @@ def main():
             out["parity"] = parity
         if eager is not None:
             out["eager"] = eager
+        if exchange is not None:
+            out["exchange"] = exchange
+        if multi:
+            out["config"]["launch_note"] = ("N>1 runs the EAGER step (hook-driven exchange overlapped with backward): compare this `value` / n_gpus "
+                                            "with the N=1 line's `eager.value`, not with its hipGraph-replayed `value`")
         if (args.f32_line and world == 1 and args.dtype == "bf16" and not multi
                 and (args.encoder, args.height, args.width, args.batch) == ("densenet161_bts", 352, 1216, 8)):
             out["f32"] = f32_line_subprocess(args, parity)
+            arb = (parity or {}).get("f64_arbiter") or {}
+            out["config"]["f32_images_per_s"] = out["f32"].get("value")            # the configuration that meets the 1e-4 bound
+            out["config"]["f32_ms_per_step"] = out["f32"].get("ms_per_step")
+            out["config"]["f32_parity_1e-4_met"] = arb.get("met")
+            out["config"]["f32_parity_elem_max_vs_f64"] = arb.get("product_elem_max")
+            out["config"]["bf16_parity_elem_max_vs_f64"] = (arb.get("bf16_attribution") or {}).get("product_bf16_elem_max")
+            out["config"]["bf16_torch_autocast_elem_max_vs_f64"] = (arb.get("bf16_attribution") or {}).get("torch_bf16_elem_max")
         if args.lpg_op and world == 1:
             try:
                 out["roofline_lpg_op"] = lpg_op_roofline(args.batch, args.height, args.width)

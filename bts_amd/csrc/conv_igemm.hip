@@ -746,6 +746,8 @@ static int conv_fwd_impl(const bts_conv_desc_t* d, bts_stream_t stream, int* q_r
         BTS_CHECK_ARG(((uintptr_t)d->stats_ws & 3) == 0);
         if (d->y2 || d->accumulate || d->fold_elu_y || d->y_stride != d->Cout) return BTS_ERR_UNSUPPORTED;
         k.stats = (float*)d->stats_ws;
+    } else if (q_rows && (d->y2 || d->accumulate || d->fold_elu_y || d->y_stride != d->Cout)) {
+        return BTS_OK;   // the query (stats_ws is null by construction) applies the same domain: 0 rows, as the header promises
     }
     return d->dtype == BTS_F32 ? launch_fwd<F32>(k, (hipStream_t)stream, q_rows) : launch_fwd<BF16>(k, (hipStream_t)stream, q_rows);
 }

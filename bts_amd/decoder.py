@@ -242,6 +242,16 @@ class DecoderRun:
         src = f.detach()
         if src.dtype not in (torch.float32, torch.bfloat16):
             src = src.float()
+        nhwc = src.permute(0, 2, 3, 1)
+        if (not src.is_contiguous() and nhwc.is_contiguous() and src.dtype == self.dtype and src.shape[1] % self.v == 0
+                and src.data_ptr() % 16 == 0):
+            # a channels-last producer (encoder run in torch.channels_last): the tensor already IS the decoder's layout.  A skip
+            # feature is used in place (read-only; `_version` is re-checked in backward), the dense feature takes its ReLU
+            # (bts.py:198) in one same-layout pass; gradients go back as channels-last views -- no transposes either way.
+            a = Act(ops.affine_act(nhwc, None, None, ACT_RELU) if relu else nhwc)
+            self.feat_acts.append(a)
+            self.feat_src.append(("cl", relu, f, f._version))
+            return a
         if not src.is_contiguous():
             src = src.contiguous()
         a = Act(ops.nchw_to_nhwc(src, self.dtype, relu))
@@ -646,7 +656,18 @@ class DecoderRun:
             self.grads[name + ".weight"] = gw_arena[off:off + n_el].view(shape)
         self.dwp_arena = None
         gfeats = []
-        for a, (relu_src, Cc, sdt) in zip(self.feat_acts, self.feat_src):
+        for a, src in zip(self.feat_acts, self.feat_src):
+            if src[0] == "cl":                               # channels-last feature (feature()): gradient returned as a view
+                _, relu, f, version = src
+                if not relu and f._version != version:
+                    raise BtsAmdError("a channels-last encoder feature was modified in place between the decoder's forward and "
+                                      "backward (the decoder reads it without a copy)")
+                g = a.g
+                if g is not None and relu:
+                    g = ops.act_bwd(g, a.t, ACT_RELU, out=g)
+                gfeats.append(None if g is None else g.permute(0, 3, 1, 2))
+                continue
+            relu_src, Cc, sdt = src
             gfeats.append(None if a.g is None else ops.nhwc_to_nchw(a.g, Cc, relu_src, out_dtype=sdt))
         # feature() was called for skips 0..3 then the dense map
         return gfeats, self.grads

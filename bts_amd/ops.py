@@ -71,11 +71,31 @@ def _multi_args(eqs, ks, divs):
     return n, B, h, w, kk, dv
 
 
+def _check_multi(plane_eqs, ks, full_maps, coarse_outs, what):
+    """Shared argument checks of the multi-problem LPG launches: the kernels take raw pointers, so a wrong dtype / stride / shape
+    would be silently wrong results, not an error."""
+    n = len(plane_eqs)
+    if not (1 <= n <= 4 and len(ks) == n):
+        raise BtsAmdError("%s: 1..4 problems with one k each (got %d plane_eqs, %d ks)" % (what, n, len(ks)))
+    for e, k in zip(plane_eqs, ks):
+        _lib.require_gpu(e)
+        if not (e.dim() == 4 and e.shape[3] == 4 and e.dtype == torch.float32 and e.is_contiguous() and int(k) >= 1):
+            raise BtsAmdError("%s: plane_eq must be contiguous f32 [B,h,w,4] (got %s %s)" % (what, tuple(e.shape), e.dtype))
+    for name, ts, shape_of in (("depth map", full_maps, lambda e, k: (e.shape[0], e.shape[1] * k, e.shape[2] * k)),
+                               ("plane gradient", coarse_outs, lambda e, k: tuple(e.shape))):
+        if ts is None:
+            continue
+        if len(ts) != n:
+            raise BtsAmdError("%s: %d %ss for %d problems" % (what, len(ts), name, n))
+        for t, e, k in zip(ts, plane_eqs, ks):
+            if not (tuple(t.shape) == shape_of(e, k) and t.dtype == torch.float32 and t.is_contiguous() and t.device == e.device):
+                raise BtsAmdError("%s: %s must be contiguous f32 %s on %s (got %s %s)" % (what, name, shape_of(e, k), e.device,
+                                                                                        tuple(t.shape), t.dtype))
+
+
 def lpg_fwd_multi(plane_eqs, ks, depth_divs=None, outs=None):
     """Several LPG problems (<= 4; e.g. the k = 8 / 4 / 2 heads of one batch) in ONE launch (bts_lpg_fwd_multi)."""
-    for e in plane_eqs:
-        _lib.require_gpu(e)
-        assert e.shape[3] == 4 and e.dtype == torch.float32 and e.is_contiguous()
+    _check_multi(plane_eqs, ks, outs, None, "lpg_fwd_multi")
     divs = depth_divs or [1.0] * len(ks)
     if outs is None:
         outs = [torch.empty((e.shape[0], e.shape[1] * k, e.shape[2] * k), dtype=torch.float32, device=e.device) for e, k in zip(plane_eqs, ks)]
@@ -88,6 +108,7 @@ def lpg_fwd_multi(plane_eqs, ks, depth_divs=None, outs=None):
 def lpg_bwd_multi(grad_depths, plane_eqs, ks, depth_divs=None, outs=None):
     divs = depth_divs or [1.0] * len(ks)
     grad_depths = [g.contiguous() for g in grad_depths]
+    _check_multi(plane_eqs, ks, grad_depths, outs, "lpg_bwd_multi")
     if outs is None:
         outs = [torch.empty_like(e) for e in plane_eqs]
     n, B, h, w, kk, dv = _multi_args(plane_eqs, ks, divs)

@@ -50,6 +50,11 @@ class GradAllReducer:
         self._works = []
         self._hooks = []
         self._defer = False
+        # diagnostics of the exchange (bench.py --gpus N): time the compute stream spends waiting for collectives AFTER the last
+        # gradient of the backward pass (finish()), i.e. the part of the exchange nothing overlapped
+        self.timing = False
+        self._exposed = []       # (event before the waits, event after them) per finish(), or wall-clock seconds without a GPU
+        self.fraction_log = []   # per step: [(bucket, hooks fired at its launch / hooks of the step)] (launch_log is reset per step)
         self._build(bucket_bytes, tail_bytes)
 
     def _build(self, bucket_bytes, tail_bytes):
@@ -106,6 +111,9 @@ class GradAllReducer:
             self._defer = False
 
     def _reset(self):
+        if self.timing and self.launch_log:
+            total = float(max(1, len(self.params)))
+            self.fraction_log.append([(bi, fired / total) for bi, fired in self.launch_log])
         self._pending = {bi: len(ps) for bi, (_, ps) in enumerate(self.buckets)}
         self._works = []
         self._fired = 0
@@ -135,9 +143,52 @@ class GradAllReducer:
             if n > 0:                      # unused parameters (e.g. ResNet fc.*): still exchange, grads are zero
                 self._pending[bi] = 0
                 self._launch(bi)
+        self._wait_all()
+
+    def _wait_all(self):
+        """Wait for every launched exchange.  On RCCL `wait()` makes the CURRENT STREAM wait (the host returns at once), so with
+        `timing` the exposed part is measured on the device: one event behind the last kernel of the backward pass, one behind
+        the waits."""
+        gpu = self.timing and self.collective and bool(self.buckets) and self.buckets[0][0].is_cuda
+        if gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        elif self.timing:
+            import time
+            t0 = time.perf_counter()
         for bi, w in self._works:
             w.wait()
+        if gpu:
+            e1.record()
+            self._exposed.append((e0, e1))
+        elif self.timing:
+            self._exposed.append(time.perf_counter() - t0)
         self._works = []
+
+    def exchange_stats(self):
+        """{'exposed_comm_ms': mean per step of the time the step waited for collectives after its last gradient,
+        'bucket_launch_fraction': per bucket, the mean fraction of the step's gradient hooks that had fired when its exchange was
+        launched (1.0 = launched by the very last gradient: nothing left to overlap with), 'bucket_mbytes': sizes}.
+        Synchronises the device.  Collected only while `timing` is True."""
+        ms = []
+        for e in self._exposed:
+            if isinstance(e, tuple):
+                e[1].synchronize()
+                ms.append(e[0].elapsed_time(e[1]))
+            else:
+                ms.append(e * 1e3)
+        if self.launch_log:                       # the step in flight
+            total = float(max(1, len(self.params)))
+            steps = self.fraction_log + [[(bi, fired / total) for bi, fired in self.launch_log]]
+        else:
+            steps = self.fraction_log
+        frac = {}
+        for st in steps:
+            for bi, f in st:
+                frac.setdefault(bi, []).append(f)
+        return {"exposed_comm_ms": round(sum(ms) / len(ms), 4) if ms else None, "steps": len(ms),
+                "bucket_launch_fraction": [round(sum(frac[bi]) / len(frac[bi]), 4) if bi in frac else None for bi in range(len(self.buckets))],
+                "bucket_mbytes": [round(f.numel() * f.element_size() / 2 ** 20, 2) for f, _ in self.buckets]}
 
     def reduce_all(self):
         """Exchange every bucket NOW, on the current stream, and turn the sums into means.  For steps whose backward ran
@@ -149,9 +200,7 @@ class GradAllReducer:
         for bi in range(len(self.buckets)):
             self._pending[bi] = 0
             self._launch(bi)
-        for bi, w in self._works:
-            w.wait()
-        self._works = []
+        self._wait_all()
 
     def remove(self):
         for h in self._hooks:
@@ -212,7 +261,6 @@ class BufferSync:
                 if b is not None:
                     by_key.setdefault((b.dtype, b.device), []).append((m, name, b))
         if not self.flattened:
-            self.sets = [[b for _, _, b in v] for v in by_key.values()]
             return
         seen = {}
         with torch.no_grad():
@@ -237,25 +285,30 @@ class BufferSync:
         `register_buffer` after construction silently replace them, and a broadcast of the flat tensor would then sync nothing."""
         return all(m._buffers.get(name) is not None and m._buffers[name].data_ptr() == ptr for m, name, ptr in self._views)
 
+    def _live_sets(self):
+        """The module's buffers AS THEY ARE NOW, one list per (dtype, device), a shared buffer once: the non-flattened path looks
+        them up on every call, so a later `.to()` / `load_state_dict(assign=True)` can never leave the sync pointing at dead tensors."""
+        by_key, seen = {}, set()
+        for m in self._module.modules():
+            for b in m._buffers.values():
+                if b is not None and id(b) not in seen:
+                    seen.add(id(b))
+                    by_key.setdefault((b.dtype, b.device), []).append(b)
+        return list(by_key.values())
+
     def __call__(self):
         if not self.active:
             return
         if self.flattened and not self._views_intact():
             # something re-bound the buffers after construction: fall back to gather / broadcast / scatter over the live ones
             self.flattened = False
-            by_key = {}
-            for m in self._module.modules():
-                for name, b in m._buffers.items():
-                    if b is not None:
-                        by_key.setdefault((b.dtype, b.device), []).append(b)
-            self.sets = list(by_key.values())
         with torch.no_grad():
             if self.flattened:
                 for flat in self.flat:
                     if flat.numel():
                         dist.broadcast(flat, src=self.src, group=self.group)
                 return
-            for bufs in self.sets:
+            for bufs in self._live_sets():
                 flat = torch.cat([b.reshape(-1) for b in bufs])
                 dist.broadcast(flat, src=self.src, group=self.group)
                 off = 0

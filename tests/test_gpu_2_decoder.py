@@ -252,3 +252,47 @@ def test_standalone_blocks_vs_oracle(block):
     with torch.no_grad():                                   # the no-grad path keeps no tape
         out2 = mod.eval()(x.to(DEV))
     assert out2.shape == ref.shape and torch.isfinite(out2).all()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_channels_last_features_are_taken_in_place(dt):
+    """A stock encoder run in torch.channels_last hands over features that already ARE the decoder's NHWC layout
+    (DecoderRun.feature): skips are read in place, the dense feature takes its ReLU (bts.py:198) in one same-layout pass,
+    gradients return as channels-last views.  Same kernels on the same values as the NCHW entry: outputs, loss and every
+    gradient must be bit-identical; a feature modified in place before backward() is refused."""
+    from bts_amd._lib import BtsAmdError
+    from bts_amd.model import silog_loss
+    feat, nf, B, H, W = [96, 96, 192, 384, 2208], 512, 2, 96, 160
+    gen = torch.Generator().manual_seed(5)
+    P = O.make_decoder_params(feat, nf, gen, randomize_bn=True)
+    feats = [f.to(dt) for f in O.make_features(feat, B, H, W, gen)]
+    focal = O.synth_focal(B, "kitti").to(DEV)
+    gt = O.synth_depth_gt(B, H, W, "kitti", gen).to(DEV)
+
+    def go(cl, poke=False):
+        dec, _ = build(feat, nf, "kitti", P, dtype=dt)
+        fs = [f.to(DEV) for f in feats]
+        if cl:
+            fs = [f.contiguous(memory_format=torch.channels_last) for f in fs]
+            assert all(not f.is_contiguous() for f in fs)
+        fs = [f.requires_grad_(True) for f in fs]
+        outs = dec(fs, focal)
+        loss = silog_loss(0.85)(outs[4], gt, gt > 1.0) + sum((o * o).mean() for o in outs[:4])
+        if poke:
+            with torch.no_grad():
+                fs[1].add_(1.0)
+        loss.backward()
+        return fs, outs, loss, {k: p.grad.clone() for k, p in dec.named_parameters()}
+    fa, oa, la, ga = go(False)
+    fb, ob, lb, gb = go(True)
+    assert torch.equal(la, lb)
+    for u, v in zip(oa, ob):
+        assert torch.equal(u, v)
+    for u, v in zip(fa, fb):
+        assert v.grad.shape == u.grad.shape and torch.equal(u.grad, v.grad.contiguous())
+        assert v.grad.permute(0, 2, 3, 1).is_contiguous()                 # came back as a view of the NHWC gradient buffer
+    # weight gradients of the split-K kernels accumulate with f32 atomics (order varies run to run): same bound as two NCHW runs
+    for k in ga:
+        assert rel(gb[k], ga[k]) < 1e-5, k
+    with pytest.raises((BtsAmdError, RuntimeError)):
+        go(True, poke=True)

@@ -532,3 +532,28 @@ def test_two_ranks_one_gpu_real_model_gradient_exchange():
             if p.is_alive():
                 p.kill()
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_model_c1_densenet121_golden_on_the_hip_path(golden_dir):
+    """BASELINE.json configs[0] through the drop-in on the GPU: `BtsModel(densenet121_bts)`, 1 x 416 x 544, nyu, eval forward,
+    against the samples the UNMODIFIED reference produced on CPU for the same seeds (tests/golden/model_c1_densenet121.npz,
+    tools/make_golden.py::gen_model_c1; same-seed construction gives the reference's exact state dict -- held on CPU by
+    tests/test_model_structure.py).  Strided samples of all five outputs, their means and L2 norms: 1e-4 (the encoder runs on
+    MIOpen here and on oneDNN there; its f32 round-off is inside that bound)."""
+    import numpy as np
+
+    from bts_amd.model import BtsModel, weights_init_xavier
+    g = np.load(golden_dir + "/model_c1_densenet121.npz")
+    torch.manual_seed(int(g["model_seed"]))
+    model = BtsModel(NS(encoder="densenet121_bts", max_depth=10.0, dataset="nyu", bts_size=512))
+    model.decoder.apply(weights_init_xavier)
+    assert int(g["n_params"]) == sum(p.numel() for p in model.parameters())
+    assert list(g["state_keys"]) == list(model.state_dict().keys())
+    model.eval().to(DEV)
+    x = torch.randn(1, 3, 416, 544, generator=torch.Generator().manual_seed(int(g["input_seed"]))).to(DEV)
+    with torch.no_grad():
+        outs = model(x, O.synth_focal(1, "nyu").to(DEV))
+    for i, o in enumerate(outs):
+        assert rel(o[:, :, ::8, ::8], torch.from_numpy(g["out%d_s8" % i])) < 1e-4, i
+        assert abs(o.double().mean().item() - float(g["out%d_mean" % i])) / abs(float(g["out%d_mean" % i])) < 1e-4, i
+        assert abs(o.double().norm().item() - float(g["out%d_l2" % i])) / float(g["out%d_l2" % i]) < 1e-4, i

@@ -96,3 +96,80 @@ def test_reference_driver_loops_on_the_hip_path(tmp_path):
                 w = want.squeeze().numpy()
                 err = np.abs(got - w).max() / np.abs(w).max()
                 assert err < 1e-4, err
+
+    # ---- the same test loop with the saved payload formed on the device (bts_test.py:179-185): the uint16
+    # image of every sample must equal what the reference computes on the host from the f32 map it copied back -- bit for bit
+    batched = [{"image": torch.cat([s["image"] for s in samples]), "focal": torch.cat([s["focal"] for s in samples])}]
+    pay = ref_loop.test_loop_device(bts_mod, targs, batched)
+    assert len(pay) == 2 and all(p.dtype == np.uint16 and p.shape == (H, W) for p in pay)
+    for p, d in zip(pay, preds[0]):
+        want = (d * 256.0).astype(np.uint16)
+        # a batch of 2 and two batches of 1 run the same per-image arithmetic in the decoder; MIOpen may pick another encoder
+        # kernel for another batch size: allow one count on a handful of pixels, nothing more
+        diff = np.abs(p.astype(np.int32) - want.astype(np.int32))
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-2, (diff.max(), (diff > 0).mean())
+    pay1 = ref_loop.test_loop_device(bts_mod, targs, samples)          # batch 1, as the reference runs it: exact
+    for p, d in zip(pay1, preds[0]):
+        assert np.array_equal(p, (d * 256.0).astype(np.uint16))
+    # ---- online_eval (bts_main.py:250-319) on the device kernels against the reference-style host loop
+    eargs = NS(**{**vars(targs), "min_depth_eval": 1e-3, "max_depth_eval": 80.0, "do_kb_crop": False, "garg_crop": True, "eigen_crop": False})
+    model_e = ref_loop._load_for_test(bts_mod, targs)
+    gen = torch.Generator().manual_seed(31)
+    esamples = []
+    for i in range(3):
+        s = _batches(1, 1, H, W, "kitti", 40 + i)[0]
+        esamples.append({"image": s["image"], "focal": s["focal"], "depth": s["depth"], "has_valid_depth": i != 1})
+    host = ref_loop.online_eval_host(model_e, esamples, eargs)
+    dev = ref_loop.online_eval_device(model_e, esamples, eargs, log=lines.append)
+    assert dev.shape == (10,) and any("Computing errors for 2 eval samples" in ln for ln in lines)
+    for i in range(9):
+        assert abs(dev[i].item() - host[i]) <= 1e-4 * max(1.0, abs(host[i])), (i, dev[i].item(), host[i])
+    # a batch of all three at once (has_valid_depth per entry): the same means
+    stacked = [{"image": torch.cat([s["image"] for s in esamples]), "focal": torch.cat([s["focal"] for s in esamples]),
+                "depth": torch.cat([s["depth"] for s in esamples]), "has_valid_depth": [True, False, True]}]
+    dev_b = ref_loop.online_eval_device(model_e, stacked, eargs)
+    for i in range(9):
+        assert abs(dev_b[i].item() - host[i]) <= 2e-3 * max(1.0, abs(host[i])), (i, dev_b[i].item(), host[i])
+
+
+def test_train_batch_pipeline_feeds_the_step():
+    """SURVEY.md 8f row 2 wired: decoded samples (uint8 RGB + int32 depth payload, as PIL hands them over) -> pinned staging ->
+    H2D on a copy stream one batch ahead -> bts_preprocess_train -> the reference's collated batch on the device, consumed by a
+    train step.  Checker: the oracle's numpy restatement of DataLoadPreprocess (oracle/data_oracle.py) with the SAME draws."""
+    import random
+
+    from bts_amd import loops
+    from oracle import data_oracle as D
+    Hs, Ws, H, W, B, ds = 80, 160, 64, 96, 2, "kitti"
+    rng = np.random.RandomState(3)
+    decoded = [(rng.randint(0, 256, size=(Hs, Ws, 3)).astype(np.uint8), rng.randint(0, 80 * 256, size=(Hs, Ws)).astype(np.int32),
+                721.5377) for _ in range(3 * B)]
+    random.seed(7)
+    np.random.seed(7)
+    pipe = loops.TrainBatchPipeline(iter(decoded), B, H, W, ds, device="cuda")
+    got = list(pipe)
+    assert len(got) == 3
+    for bi, batch in enumerate(got):
+        assert tuple(batch["image"].shape) == (B, 3, H, W) and tuple(batch["depth"].shape) == (B, 1, H, W)
+        assert batch["focal"].dtype == torch.float64 and batch["image"].is_cuda
+        for b in range(B):
+            img, dep, _ = decoded[bi * B + b]
+            ap = batch["aug_params"][b]
+            pd = {"crop_x": ap.crop_x, "crop_y": ap.crop_y, "flip": ap.flip, "augment": ap.augment, "gamma": ap.gamma,
+                  "brightness": ap.brightness, "colors": np.array([ap.color[0], ap.color[1], ap.color[2]])}
+            wi, wd, _ = D.preprocess_train(img, dep, pd, H, W, ds)
+            assert np.array_equal(batch["depth"][b].cpu().numpy(), wd), (bi, b)
+            gi = batch["image"][b].cpu().numpy()
+            if ap.augment:      # powf against numpy's pow: an ulp, as in test_preprocess_train_vs_reference_golden
+                assert np.abs(gi - wi).max() <= 2e-6, (bi, b)
+            else:
+                assert np.array_equal(gi, wi), (bi, b)
+    # and a step on it: the drop-in model + silog on the pipeline's batch
+    bts_mod = _load_dropin()
+    args = NS(encoder="densenet121_bts", dataset=ds, max_depth=80.0, bts_size=512)
+    torch.manual_seed(0)
+    model = bts_mod.BtsModel(args).cuda().train()
+    outs = model(got[0]["image"], got[0]["focal"])
+    loss = bts_mod.silog_loss(0.85)(outs[4], got[0]["depth"], got[0]["depth"] > 1.0)
+    loss.backward()
+    assert torch.isfinite(loss).item()

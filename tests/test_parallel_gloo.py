@@ -205,10 +205,17 @@ def _step_worker(rank, world, port, q):
         n_dec = len(list(net.decoder.parameters()))
         assert {id(p) for p in red.buckets[0][1][:n_dec]} == {id(p) for p in net.decoder.parameters()}
         x = torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(rank))
+        red.timing = True                      # bench.py --gpus N: exposed_comm_ms / bucket_launch_fraction of the line
         red.zero_grad()
         net(x).pow(2).mean().backward()
         log = list(red.launch_log)
         red.finish()
+        stats = red.exchange_stats()
+        assert stats["steps"] == 1 and stats["exposed_comm_ms"] is not None and stats["exposed_comm_ms"] >= 0.0
+        fr = stats["bucket_launch_fraction"]
+        assert len(fr) == len(red.buckets) and fr[-1] == 1.0 and fr[0] < 1.0, stats      # tail closes the step; decoder bucket early
+        assert len(stats["bucket_mbytes"]) == len(red.buckets)
+        red.timing = False
         # every bucket was launched from a hook (none left for finish()); the bucket that holds the decoder went on the wire
         # while encoder gradients were still outstanding -- its launch happened before the last hook of the step fired -- and
         # the exchange that closes the step is the small tail bucket.  (The autograd engine does not promise the order in
@@ -314,6 +321,15 @@ def _buffer_worker(rank, world, port, flatten, q):
             got = [torch.zeros_like(bn.running_mean) for _ in range(world)]
             dist.all_gather(got, bn.running_mean)
             assert all(torch.equal(g, torch.full_like(g, 10.0)) for g in got), "stale views: the re-bound buffer was not synchronised"
+            # ... and a SECOND re-bind after the fallback (advisor item of round 5: the fallback once kept the list of live buffers it
+            # found the first time): the non-flattened path looks the buffers up on every call
+            bn._buffers["running_var"] = torch.full_like(bn.running_var, 20.0 + rank)
+            bn._buffers["running_mean"] = torch.full_like(bn.running_mean, 30.0 + rank)
+            sync()
+            for name, want in (("running_var", 20.0), ("running_mean", 30.0)):
+                got = [torch.zeros_like(bn._buffers[name]) for _ in range(world)]
+                dist.all_gather(got, bn._buffers[name])
+                assert all(torch.equal(g, torch.full_like(g, want)) for g in got), "second re-bind of %s not synchronised" % name
         q.put((rank, "ok"))
     except Exception as e:   # noqa: BLE001
         import traceback

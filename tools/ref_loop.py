@@ -17,6 +17,9 @@ from them -- so a `-m gpu` test can put the same sequence of calls on the real k
                  `.cuda()`, parameter count via numpy, then under `torch.no_grad()` per sample: `.cuda()`, five outputs,
                  `depth_est.cpu().numpy().squeeze()` and `lpgNxN[0].cpu().numpy().squeeze()` appended to five lists.
 
+  test_loop_device / online_eval_device / train_batches_device: the same loops with the work either side of the model on the
+                 device kernels (bts_amd/loops.py: uint16 payload, compute_errors, sample preprocessing) -- SURVEY.md 8f rows 2-4.
+
 `model_module` is whatever `from bts import *` would have bound (the drop-in module): it must provide BtsModel, silog_loss,
 weights_init_xavier, bn_init_as_tf -- nothing else is assumed.
 """
@@ -124,3 +127,45 @@ def test_loop(model_module, args, samples, log=print):
             pred_2x2s.append(lpg2x2[0].cpu().numpy().squeeze())
             pred_1x1s.append(reduc1x1[0].cpu().numpy().squeeze())
     return pred_depths, pred_8x8s, pred_4x4s, pred_2x2s, pred_1x1s
+
+
+def _load_for_test(model_module, args):
+    model = model_module.BtsModel(params=args)
+    model = torch.nn.DataParallel(model)
+    model.load_state_dict(torch.load(args.checkpoint_path)["model"])
+    model.eval()
+    model.cuda()
+    return model
+
+
+def test_loop_device(model_module, args, samples, keep_lpg=False):
+    """bts_test.py's `test` with the saved payload formed on the device (bts_test.py:119-124 + 179-185): the uint16 images that
+    are written as PNG, one device -> host copy of 2 bytes per pixel per batch instead of five f32 maps per image."""
+    from bts_amd import loops
+    model = _load_for_test(model_module, args)
+    return loops.predict_payloads(model, samples, args.dataset, device="cuda", keep_lpg=keep_lpg)
+
+
+def online_eval_host(model, eval_samples, args):
+    """bts_main.py:250-319 as the reference does it (per image: five-output forward, prediction and ground truth to the host,
+    numpy masks + compute_errors) -- the checker of online_eval_device.  Uses the oracle's restatement of the host arithmetic."""
+    from oracle import eval_oracle as E
+    em = np.zeros(10, dtype=np.float64)
+    with torch.no_grad():
+        for s in eval_samples:
+            if not s.get("has_valid_depth", True):
+                continue
+            pred = model(s["image"].cuda(), s["focal"].cuda())[4].cpu().numpy().squeeze()
+            gt = s["depth"].cpu().numpy().squeeze()
+            pf, valid = E.eval_prepare(pred, gt, args.min_depth_eval, args.max_depth_eval, args.dataset, args.do_kb_crop,
+                                       args.garg_crop, args.eigen_crop)
+            em[:9] += np.array(E.compute_errors(gt[valid], pf[valid]), dtype=np.float64)
+            em[9] += 1
+    return em / em[9]
+
+
+def online_eval_device(model, eval_samples, args, log=None):
+    """The same evaluation on `bts_eval_errors`: nothing but the 10-float measure vector leaves the device."""
+    from bts_amd import loops
+    return loops.online_eval(model, eval_samples, args.dataset, args.min_depth_eval, args.max_depth_eval, args.do_kb_crop,
+                             args.garg_crop, args.eigen_crop, device="cuda", log=log)
