@@ -114,6 +114,8 @@ def _wgrad_kernel(dtype, cout, radius1, up, n, hg, wg, cols=None):
         return "conv_wgrad_c1<%s>" % _dn(dtype)
     if radius1 and not up and 1 < cout <= 128 and bf and big_map:
         return "conv_wgrad_halo_tr<bf16>"
+    if radius1 and up and cout in (32, 64) and bf and big_map:       # r6: launch_wgrad_halo_tr_up (dz pixel stride == cout)
+        return "conv_wgrad_halo_tr_up<bf16>"
     if 32 < cout <= 64 and bf:
         return "conv_wgrad_ring<bf16,64x256>"
     if radius1 and up and cout <= 64 and bf and big_map:

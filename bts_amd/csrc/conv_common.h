@@ -526,6 +526,7 @@ int launch_halo_wide(const ConvK& k, hipStream_t st, int force);
 // conv_wgrad_tr.hip: bf16 weight gradient of the narrow radius-1 3x3 layers (Cout <= 64) on 2-D pixel tiles: LDS-DMA patch + dz tile,
 // transposing reads, taps as row offsets; BTS_ERR_UNSUPPORTED outside its domain
 int launch_wgrad_halo_tr(const ConvK& k, hipStream_t st);
+int launch_wgrad_halo_tr_up(const ConvK& k, hipStream_t st);   // sub-pixel up-convolution, 32 output channels (r6)
 
 // conv_wgrad_tr.hip: 64 co x 256 column ring form of the transposing weight-gradient kernel (32 < Cout <= 64, bf16)
 int launch_wgrad_ring64(const ConvK& k, hipStream_t st);

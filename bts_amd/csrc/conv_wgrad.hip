@@ -601,6 +601,13 @@ static int launch_wgrad(const ConvK& k0, hipStream_t st) {
         const int rc = launch_wgrad_halo_tr(k, st);
         if (rc != BTS_ERR_UNSUPPORTED) return rc;
     }
+    // r6: sub-pixel up-convolutions with exactly 32 / 64 output channels at that pixel stride, on maps of >= 256 tiles (upconv1, upconv2):
+    // both operands staged once per tile as they lie, every (phase, tap) a row offset of transposing reads (conv_wgrad_tr.hip,
+    // conv_wgrad_halo_tr_up); every other shape keeps the ring / scatter kernels below
+    if (T::kBytes == 2 && k.halo_ok && k.nphase == 4 && k.T == 4 && ceil_div(k.Wg, 32) * ceil_div(k.Hg, 8) * k.N >= 256) {
+        const int rc = launch_wgrad_halo_tr_up(k, st);
+        if (rc != BTS_ERR_UNSUPPORTED) return rc;
+    }
     // 64-output-channel layers (upconv2, and every other 33..64-channel bf16 layer outside the halo form): 64 x 256 ring form of the
     // transposing kernel.  Measured against the LDS-scatter kernels (gpurun r03k): conv2 481 -> 368 us, upconv2 168 -> 123 us.
     if (T::kBytes == 2 && k.Cout > 32 && k.Cout <= 64) {

@@ -255,6 +255,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr(const ConvK a) {
 // problem): 128 x 128 two-stage 758 TF, 128 x 128 four half-stages 881, 128 x 256 two-stage 743, 128 x 256 three-stage ring
 // 953, 256 x 256 rings 814-827 (profiles/r03_wgrad_pipe_probe.jsonl).
 // RAW / WAR argument: see conv_igemm_dma's ring schedule (conv_igemm.hip), it is the same.
+// r6 (BTS_RING_XCD_SPLIT = 1): which workgroups share an XCD (= an L2).  Workgroups are dealt to the 8 XCDs round-robin by their linear
+// index.  The launchers used a (tiles, splits) grid with the XCD remap applied to the tile index alone, which put the SAME output tile
+// of EVERY pixel split on one XCD: 32 resident workgroups reading 16 different pixel ranges, every dZ row fetched through all eight
+// L2s and every X row through most of them (fabric traffic 4.4x the algorithmic bytes, profiles/pmc_traffic.json r5).  Now the grid
+// is one-dimensional and the remap runs over (phase, split, tile) with the tile innermost: an XCD owns whole pixel splits, all output
+// tiles of a split run side by side on one L2 and walk the same 64-pixel chunks at the same time, so a staged row is fetched from the
+// fabric once per split instead of once per XCD.
+#ifndef BTS_RING_XCD_SPLIT
+#define BTS_RING_XCD_SPLIT 1
+#endif
 template <int WR, int WC, int NST>
 __device__ __forceinline__ void wgrad_ring_body(const ConvK& a, const int tile_index, const int split, const int phase, const bool single) {
     constexpr int NT = WR * WC * 64, TM = WR * 64, TN = WC * 64;
@@ -268,7 +278,7 @@ __device__ __forceinline__ void wgrad_ring_body(const ConvK& a, const int tile_i
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int L = remap_xcd(tile_index, a.n_co_tiles * a.n_col_tiles);
+    const int L = BTS_RING_XCD_SPLIT ? tile_index : remap_xcd(tile_index, a.n_co_tiles * a.n_col_tiles);
     const int co_tile = L % a.n_co_tiles, col_tile = L / a.n_co_tiles;
     const int pa = phase >> 1, pb = phase & 1;
     const char* zero = (const char*)kZeroPage;
@@ -441,7 +451,23 @@ __device__ __forceinline__ void wgrad_ring_body(const ConvK& a, const int tile_i
 
 template <int WR, int WC, int NST>
 __global__ __launch_bounds__(WR* WC * 64) void conv_wgrad_ring(const ConvK a) {
+#if BTS_RING_XCD_SPLIT
+    // 1-D grid of nphase x splits x tiles workgroups (ring_grid below): logical index = XCD-contiguous remap of the linear one
+    const int tiles = a.n_co_tiles * a.n_col_tiles, splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    const int L = remap_xcd((int)blockIdx.x, (int)gridDim.x);
+    const int per_phase = tiles * splits, phase = L / per_phase, rest = L - phase * per_phase;
+    wgrad_ring_body<WR, WC, NST>(a, rest % tiles, rest / tiles, phase, splits == 1);
+#else
     wgrad_ring_body<WR, WC, NST>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, gridDim.y == 1);
+#endif
+}
+// grid of conv_wgrad_ring for (tiles, splits, phases)
+static inline dim3 ring_grid(int tiles, int splits, int nphase) {
+#if BTS_RING_XCD_SPLIT
+    return dim3((unsigned)(tiles * splits * nphase));
+#else
+    return dim3(tiles, splits, nphase);
+#endif
 }
 
 // Grouped form (r4): up to WG_GROUP_MAX independent weight gradients in ONE launch.  Split-K over pixels costs a full-chip set of f32
@@ -461,7 +487,8 @@ static_assert(sizeof(WgradGroup) <= 4096, "kernel argument segment");
 
 template <int WR, int WC, int NST>
 __global__ __launch_bounds__(WR* WC * 64) void conv_wgrad_ring_group(const WgradGroup g) {
-    const int b = (int)blockIdx.x;
+    // (r6) logical index = XCD-contiguous remap of the linear one: an XCD owns runs of (problem, split, tile) with the tile innermost
+    const int b = BTS_RING_XCD_SPLIT ? remap_xcd((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     // constant indices into the by-value argument (a dynamic index would copy the 496-byte descriptor through scratch)
 #define BTS_GROUP_CASE_(I)                                                                                              \
     if (I < g.n && b >= g.first[I] && b < g.first[I + 1]) {                                                              \
@@ -637,6 +664,174 @@ __global__ __launch_bounds__(576) void conv_wgrad_halo_tr(const ConvK a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the narrow SUB-PIXEL up-convolutions (upconv1: nearest x2 + 3x3, 64 -> 32 channels; upconv2: 128 -> 64;
+// bts.py:69-80, 181, 189) in the same form (r6).  An up-convolution runs as four output phases (py, px) of four 2x2 taps each on
+// the LOW-resolution input, so its weight gradient is sixteen (phase, tap) blocks
+//
+//     dW[ph][t][co][ci] = sum over low-res pixels (y, x) of  dz[2y + py][2x + px][co] * x[y + dy_t][x + dx_t][ci]
+//
+// which the unpack launch folds back onto the 3x3 taps.  conv_wgrad_halo_up (conv_wgrad.hip) transposed both operands through
+// 2-byte LDS scatters (upconv1: 168 us, 0.13 of the MFMA peak, the slowest launch of the narrow family); upconv2 ran the 64 x 256
+// ring, which re-stages the input once per tap (120 us).  Here, as in conv_wgrad_halo_tr, both operands are staged ONCE per tile as
+// they lie in memory and every (phase, tap) reads them at a row offset:
+//
+//   * tile = TH x 32 low-res pixels; the (TH+2) x 34 input patch of one 64-channel chunk: rows = pixels, 128 B;
+//   * dz, NCA = 1 (32 output channels at pixel stride 32): the two fine pixels (2x, 2x+1) of a fine row are 128 CONTIGUOUS bytes =
+//     one LDS row whose 64-byte halves are the phases px = 0 / 1; one row set per py (TH = 4: 2 x 128 rows per tile);
+//     NCA = 2 (64 output channels at pixel stride 64): one row per fine pixel, one row set per phase (TH = 2: 4 x 64 rows);
+//   * workgroup = 16 waves, wave = (phase, tap): A fragments from the phase's row set (half px / halves ca), B fragments from the
+//     patch at the tap's row offset; NCA x 2 accumulator tiles per wave over a contiguous range of tiles; two stages (58 / 49 KiB),
+//     one barrier per tile, the next tile's DMA in flight under the k-steps of this one; one set of atomics per workgroup.
+// Domain (launcher): bf16, Cout == dz_stride == 32 or 64, nphase 4 x T 4; anything else keeps the older kernels.
+template <int NCA>
+__global__ __launch_bounds__(1024) void conv_wgrad_halo_tr_up(const ConvK a) {
+    constexpr int TH = NCA == 1 ? 4 : 2, TW = 32, PW = TW + 2, PR = (TH + 2) * PW;   // 204 / 136 patch rows
+    constexpr int ZR0 = (PR + 3) / 4 * 4, ZSET = TH * TW, NSET = NCA == 1 ? 2 : 4;   // first dz row; rows per set; row sets
+    constexpr int ROWS = ZR0 + NSET * ZSET, STAGE = ROWS * 128;                      // 464 / 392 rows
+    constexpr int NW = 16, RPP = NW * 8, NPASS = (ROWS + RPP - 1) / RPP;             // 128 rows per DMA pass, 4 passes (the last one partial)
+    constexpr int ZB = NCA * 64;                                                     // bytes of one fine pixel of dz
+    static_assert(ZR0 % 4 == 0 && ZR0 >= PR && RPP % 4 == 0 && ZSET % 4 == 0, "swap phase of a DMA row must depend on the lane only");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = blockIdx.y;
+    const char* zero = (const char*)kZeroPage;
+    const int tiles_x = (a.Wg + TW - 1) / TW, tiles_y = (a.Hg + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * a.N;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
+    if (t_begin >= t_end) return;
+
+    // ---- DMA roles: piece pc of row r8 of the wave's 8-row group in every pass ----------------------------------------------------
+    const int pc = lane & 7, r8 = lane >> 3;
+    const int lp = pc ^ (((r8 >> 1) & 1) << 2);                            // logical 16-byte piece (half swap; row phase = r8 phase)
+    const int cv = chunk * 8 + lp;
+    const char* xbase = nullptr;
+    uint32_t xsb = 0;
+    if (cv < a.KV) {
+        int seg, seg_end; const char* sp; uint32_t coffB;
+        pick_seg_b(a, cv, 16, seg, sp, xsb, coffB, seg_end);
+        xbase = sp + coffB;
+    }
+    const char* zbase = a.dz + lp * 16;              // NCA 1: pieces 0..3 fine pixel 2x, 4..7 fine pixel 2x + 1; NCA 2: 64 channels of one
+    auto fire = [&](int tile, char* stage) {
+        const int tx = tile % tiles_x, r1 = tile / tiles_x;
+        const int y0 = (r1 % tiles_y) * TH, n = r1 / tiles_y, x0 = tx * TW;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int rowg = p * RPP + wave * 8;                           // wave-uniform
+            if (rowg < ROWS) {
+                const int row = rowg + r8;
+                const char* src = zero;
+                if (row < PR) {
+                    const int py = row / PW, px = row - py * PW;
+                    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+                    if (xbase && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx)
+                        src = xbase + (size_t)((uint32_t)((n * a.Hx + iy) * a.Wx + ix) * xsb);
+                } else if (row >= ZR0) {
+                    const int zr = row - ZR0;
+                    const int set = zr / ZSET, q = zr - set * ZSET;        // powers of two
+                    const int ly = y0 + (q >> 5), lx = x0 + (q & 31);
+                    const int fy = 2 * ly + (NCA == 1 ? set : (set >> 1)), fx = 2 * lx + (NCA == 1 ? 0 : (set & 1));
+                    if (ly < a.Hg && lx < a.Wg) src = zbase + (size_t)((uint32_t)((n * a.Hy + fy) * a.Wy + fx) * (uint32_t)ZB);
+                }
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(stage + rowg * 128), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- fragment roles: wave = (phase, tap) ------------------------------------------------------------------------------------
+    const int ph = wave >> 2, py = ph >> 1, px = ph & 1;
+    int dy, dx, ioy, iox;
+    decode_tap(a.taps[wave], dy, dx, ioy, iox);                            // a.T == 4, a.nphase == 4 (launcher): tap index = wave
+    const int i16 = lane & 15, g = lane >> 4;
+    const int key = tr_key(i16), cg = tr_cg(i16), kb = g >> 1, chh = g & 1;
+    const int inrow = chh * 32 + cg * 8;
+    const int swA = (key >> 1) & 1;
+    const int cB = (1 + dy) * PW + 1 + dx + kb * 8 + key;
+    const int swB0 = (cB >> 1) & 1;
+    const uint32_t lds0 = lds_addr(smem);
+    uint32_t aA[NCA], bB[2][2];                                            // byte offsets inside a stage
+#pragma unroll
+    for (int ca = 0; ca < NCA; ++ca) {
+        const int set = NCA == 1 ? py : ph, half = NCA == 1 ? px : ca;
+        aA[ca] = (uint32_t)((ZR0 + set * ZSET + kb * 8 + key) * 128 + ((half ^ swA) << 6) + inrow);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int par = 0; par < 2; ++par) bB[cb][par] = (uint32_t)(cB * 128 + ((cb ^ swB0 ^ par) << 6) + inrow);
+
+    f32x16_t acc[NCA][2];
+#pragma unroll
+    for (int ca = 0; ca < NCA; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ca][cb][r] = 0.f;
+
+    Frag fa[2][NCA], fb[2][2];
+    // the NCA + 2 fragments of k-step S (tile row S >> 1, half S & 1) into register set SET; R < NCA: dz, else the two 32-channel halves of x
+    auto read_frag = [&](auto s_c, auto set_c, auto r_c, uint32_t sbase) {
+        constexpr int S = decltype(s_c)::value, SET = decltype(set_c)::value, R = decltype(r_c)::value;
+        constexpr int ty = S >> 1, h = S & 1;
+        if constexpr (R < NCA) {
+            tr_issue<S * 16 * 128>(fa[SET][R].lo, sbase + aA[R]);
+            tr_issue<S * 16 * 128 + 512>(fa[SET][R].hi, sbase + aA[R]);
+        } else {
+            constexpr int cb = R - NCA, OFF = (ty * PW + h * 16) * 128;
+            tr_issue<OFF>(fb[SET][cb].lo, sbase + bB[cb][ty & 1]);
+            tr_issue<OFF + 512>(fb[SET][cb].hi, sbase + bB[cb][ty & 1]);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    constexpr int NKS = 2 * TH;                                            // 8 / 4 k-steps of 16 pixels
+    fire(t_begin, smem);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int cur = (tile - t_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's pieces of the tile have landed
+        __builtin_amdgcn_s_barrier();                                      // ... everybody's; and the other stage is no longer read
+        if (tile + 1 < t_end) fire(tile + 1, smem + (cur ^ 1) * STAGE);    // in flight under the k-steps below
+        const uint32_t sbase = lds0 + cur * STAGE;
+        static_for_n<NCA + 2>([&](auto r_c) { read_frag(I0{}, I0{}, r_c, sbase); });
+        static_for_n<NKS>([&](auto s_c) {
+            constexpr int S = decltype(s_c)::value, CUR = S & 1, NXT = CUR ^ 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the fragments of k-step S have returned
+            static_for_n<NCA * 2>([&](auto m_c) {
+                constexpr int m = decltype(m_c)::value, ca = m >> 1, cb = m & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                Mma<BF16>::run(frag_vec(fa[CUR][ca]), frag_vec(fb[CUR][cb]), acc[ca][cb]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (S + 1 < NKS) {                               // NCA + 2 fragments of the next k-step over the NCA * 2 MFMA shadows
+                    constexpr int lo = m * (NCA + 2) / (NCA * 2), hi = (m + 1) * (NCA + 2) / (NCA * 2);
+                    static_for_n<hi - lo>([&](auto q_c) {
+                        read_frag(std::integral_constant<int, S + 1>{}, std::integral_constant<int, NXT>{},
+                                  std::integral_constant<int, lo + decltype(q_c)::value>{}, sbase);
+                    });
+                }
+            });
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: one set of atomics per workgroup (rows = co, lanes = consecutive channels: 128-byte runs) -------------------------
+    const int frow = lane & 31, fk = lane >> 5;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int k = chunk * 64 + cb * 32 + frow;
+        if (k >= a.Ktot) continue;
+#pragma unroll
+        for (int ca = 0; ca < NCA; ++ca)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ca * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * a.Ttot + wave) * a.Ktot + k, acc[ca][cb][r]);
+            }
+    }
+}
+
 }  // namespace
 
 // 64 co x 256 columns, four waves, two stages (80 KiB: two workgroups per CU): the narrow full-resolution layers (conv2, upconv2:
@@ -662,6 +857,29 @@ int launch_wgrad_halo_tr(const ConvK& k0, hipStream_t st) {
     return BTS_OK;
 }
 
+// the sub-pixel up-convolutions with exactly 32 / 64 output channels stored at that pixel stride (upconv1 / upconv2): see conv_wgrad_halo_tr_up
+int launch_wgrad_halo_tr_up(const ConvK& k0, hipStream_t st) {
+    ConvK k = k0;
+    if (!(k.halo_ok && k.nphase == 4 && k.T == 4 && k.osc == 2 && (k.Cout == 32 || k.Cout == 64) && k.dz_stride == k.Cout))
+        return BTS_ERR_UNSUPPORTED;
+    if (!segs_fit_u32(k)) return BTS_ERR_UNSUPPORTED;
+    if ((unsigned long long)k.N * k.Hy * k.Wy * (unsigned long long)(2 * k.Cout) >= (1ull << 32)) return BTS_ERR_UNSUPPORTED;
+    if (k.Hy < 2 * k.Hg || k.Wy < 2 * k.Wg || (k.Wy & 1)) return BTS_ERR_UNSUPPORTED;
+    const bool wide = k.Cout == 64;
+    const int ntiles = ceil_div(k.Wg, 32) * ceil_div(k.Hg, wide ? 2 : 4) * k.N;
+    const int nch = ceil_div(k.KV, 8);
+    int workers = bts_cu_count() / nch;                                    // one 98 / 116 KiB workgroup per CU
+    if (workers < 1) workers = 1;
+    if (workers > ntiles) workers = ntiles;
+    const int lds = 2 * (wide ? 392 : 464) * 128;
+    static DynLdsCache lds_set[2];
+    auto kern = wide ? conv_wgrad_halo_tr_up<2> : conv_wgrad_halo_tr_up<1>;
+    if (ensure_dyn_lds((const void*)kern, lds, lds_set[wide]) != BTS_OK) return BTS_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(workers, nch), dim3(1024), (size_t)lds, st, k);
+    if (hipGetLastError() != hipSuccess) return BTS_ERR_LAUNCH;
+    return BTS_OK;
+}
+
 int launch_wgrad_ring64(const ConvK& k0, hipStream_t st) {
     ConvK k = k0;
     if (k.Cout > 64 || k.Cout <= 32) return BTS_ERR_UNSUPPORTED;
@@ -679,7 +897,7 @@ int launch_wgrad_ring64(const ConvK& k0, hipStream_t st) {
     splits = ceil_div(k.nchunks, k.chunks_per_split);
     static DynLdsCache lds_set;
     if (ensure_dyn_lds((const void*)conv_wgrad_ring<1, 4, NST>, LDS, lds_set) != BTS_OK) return BTS_ERR_LAUNCH;
-    dim3 grid(k.n_col_tiles, splits, k.nphase);
+    const dim3 grid = ring_grid(k.n_col_tiles, splits, k.nphase);
     hipLaunchKernelGGL((conv_wgrad_ring<1, 4, NST>), grid, dim3(256), (size_t)LDS, st, k);
     if (hipGetLastError() != hipSuccess) return BTS_ERR_LAUNCH;
     return BTS_OK;
@@ -710,7 +928,7 @@ int launch_wgrad_tr(const ConvK& k0, hipStream_t st) {
         splits = ceil_div(k.nchunks, k.chunks_per_split);
         static DynLdsCache lds_set;
         if (ensure_dyn_lds((const void*)conv_wgrad_ring<2, 4, NST>, LDS, lds_set) != BTS_OK) return BTS_ERR_LAUNCH;
-        dim3 grid(k.n_co_tiles * k.n_col_tiles, splits, k.nphase);
+        const dim3 grid = ring_grid(k.n_co_tiles * k.n_col_tiles, splits, k.nphase);
         hipLaunchKernelGGL((conv_wgrad_ring<2, 4, NST>), grid, dim3(512), (size_t)LDS, st, k);
         if (hipGetLastError() != hipSuccess) return BTS_ERR_LAUNCH;
         return BTS_OK;

@@ -350,7 +350,48 @@ struct TileCtx {
     bool ok;
     int w_cells, lane, cl, g;
     float max_depth;
+    // this lane's share of the head's output gradient (its KUP / 2 patch rows x KUP columns; the cell's one value for KUP = 1),
+    // loaded at the TOP of the tile iteration by prefetch_gout (r6): head_bwd sits at the bottom of the recompute chain, and a load
+    // issued there is a full memory latency nothing can hide (the 128-channel chains run one wave per SIMD)
+    float gpre[32];
 };
+
+// A/B switches of the two r6 changes (tools/chain_probe.py on candidate builds; defaults = what the measurement kept)
+#ifndef BTS_CHAIN_PRE_G
+#define BTS_CHAIN_PRE_G 1
+#endif
+#ifndef BTS_CHAIN_BATCH_DX
+#define BTS_CHAIN_BATCH_DX 1
+#endif
+
+template <int KUP>
+__device__ __forceinline__ void prefetch_gout(TileCtx& t) {
+    if constexpr (KUP == 1) {
+        t.gpre[0] = (t.ok && t.g == 0) ? t.gout[t.cell] : 0.f;
+    } else {
+        constexpr int RH = KUP / 2;                                             // patch rows per half-wave
+#pragma unroll
+        for (int i = 0; i < RH * KUP; ++i) t.gpre[i] = 0.f;
+        if (t.ok) {
+            const long j = t.cell % t.w_cells, bi = t.cell / t.w_cells;
+            const float* gp = t.gout + ((size_t)bi * KUP) * ((size_t)t.w_cells * KUP) + (size_t)j * KUP;
+#pragma unroll
+            for (int rr = 0; rr < RH; ++rr) {
+                const float* q = gp + (size_t)(t.g * RH + rr) * t.w_cells * KUP;
+                if constexpr (KUP >= 4) {
+#pragma unroll
+                    for (int c = 0; c < KUP; c += 4) {
+                        const f32x4_t tv = *(const f32x4_t*)(q + c);
+                        t.gpre[rr * KUP + c] = tv.x; t.gpre[rr * KUP + c + 1] = tv.y; t.gpre[rr * KUP + c + 2] = tv.z; t.gpre[rr * KUP + c + 3] = tv.w;
+                    }
+                } else {
+                    const float2 tv = *(const float2*)q;
+                    t.gpre[rr * KUP] = tv.x; t.gpre[rr * KUP + 1] = tv.y;
+                }
+            }
+        }
+    }
+}
 
 __device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
@@ -375,10 +416,16 @@ __device__ __forceinline__ void scatter_rows(const Act<BF16>::Regs<C>& a, char* 
 
 // gradient of the head wrt the raw 1x1 outputs of one cell (valid in lanes 0-31)
 template <int KUP>
-__device__ __forceinline__ void head_bwd(const f32x16_t& acc, const TileCtx& t, float (&gr)[3]) {
+__device__ __forceinline__ void head_bwd(const f32x16_t& acc, const TileCtx& t0, float (&gr)[3]) {
+#if BTS_CHAIN_PRE_G
+    const TileCtx& t = t0;
+#else
+    TileCtx t = t0;                                                             // loads issued here, at their use (the A side of the A/B)
+    prefetch_gout<KUP>(t);
+#endif
     if constexpr (KUP == 1) {
         const float sg = act_sigmoid(acc[0]);                                   // bts.py:93-96
-        const float go = (t.ok && t.g == 0) ? t.gout[t.cell] : 0.f;
+        const float go = t.gpre[0];
         gr[0] = go * sg * (1.f - sg);
         gr[1] = 0.f;
         gr[2] = 0.f;
@@ -387,25 +434,14 @@ __device__ __forceinline__ void head_bwd(const f32x16_t& acc, const TileCtx& t, 
         const Plane p = plane_from_raw(r0, r1, r2, t.max_depth);
         float g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f;
         if (t.ok) {
-            const long j = t.cell % t.w_cells, bi = t.cell / t.w_cells;
-            const float* gp = t.gout + ((size_t)bi * KUP) * ((size_t)t.w_cells * KUP) + (size_t)j * KUP;
             constexpr int RH = KUP / 2;                                         // patch rows per half-wave
 #pragma unroll
             for (int rr = 0; rr < RH; ++rr) {
                 const int r = t.g * RH + rr;
                 const float v = lpg_offset(r, KUP);
-                const float* q = gp + (size_t)r * t.w_cells * KUP;
                 float gv[KUP];
-                if constexpr (KUP >= 4) {
 #pragma unroll
-                    for (int c = 0; c < KUP; c += 4) {
-                        const f32x4_t tv = *(const f32x4_t*)(q + c);
-                        gv[c] = tv.x; gv[c + 1] = tv.y; gv[c + 2] = tv.z; gv[c + 3] = tv.w;
-                    }
-                } else {
-                    const float2 tv = *(const float2*)q;
-                    gv[0] = tv.x; gv[1] = tv.y;
-                }
+                for (int c = 0; c < KUP; ++c) gv[c] = t.gpre[rr * KUP + c];     // prefetch_gout
 #pragma unroll
                 for (int c = 0; c < KUP; ++c) {
                     const float u = lpg_offset(c, KUP);
@@ -516,7 +552,11 @@ struct BwdLayer {
                     const int co = 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ci = 32 * tn + (l & 31);
                     if (co < COUT && ci < C) {
                         const float v = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+#ifdef BTS_CHAIN_DIAG_NOATOMIC          // timing-only diagnostic build (tools/build_chain_candidates.sh): what the atomics cost
+                        dst[(size_t)co * ld + ci] = v;
+#else
                         atomicAdd(dst + (size_t)co * ld + ci, v);
+#endif
                     }
                 }
             }
@@ -568,10 +608,26 @@ __global__ __launch_bounds__(256, (C0 >= 128 ? 1 : ((C0 <= 32 && KUP == 1) || C0
         t.lane = lane; t.cl = cl; t.g = g; t.max_depth = a.max_depth;
         in = in_next;
         load_tile(tile + tstep, in_next);
+        // r6: the head's output gradient (head_bwd) is requested HERE, in front of the recompute chain
+#if BTS_CHAIN_PRE_G
+        prefetch_gout<KUP>(t);
+#endif
+        char* px = (char*)a.dx + ((size_t)t.cell * a.dx_stride) * 2;
+        __builtin_amdgcn_sched_barrier(0);
         f32x16_t dA[TN0];
         BwdLayer<C0, NOUT, KUP, true, 0, NTOT>::run(in, wf, wt, scr, t, dw, dA);
+        // r6: the old values of an accumulating dx, ALL of them in flight together (written inside the loop below, every 32-channel
+        // block waited for its own two loads behind the previous block's stores: TN0 memory latencies in a row)
+        u32x4_t oldall[TN0][2];
+        if (BTS_CHAIN_BATCH_DX && t.ok && a.dx_accumulate && a.dx_wide) {
+#pragma unroll
+            for (int tn = 0; tn < TN0; ++tn)
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2)
+                    if (32 * tn + 32 <= C0) oldall[tn][p2] = *(const u32x4_t*)(px + (32 * tn + 8 * (2 * p2 + g)) * 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (t.ok) {                                        // dx: 4 consecutive channels per accumulator quad
-            char* px = (char*)a.dx + ((size_t)t.cell * a.dx_stride) * 2;
 #pragma unroll
             for (int tn = 0; tn < TN0; ++tn) {
                 if (a.dx_wide && 32 * tn + 32 <= C0) {
@@ -585,7 +641,7 @@ __global__ __launch_bounds__(256, (C0 >= 128 ? 1 : ((C0 <= 32 && KUP == 1) || C0
 #pragma unroll
                     for (int p2 = 0; p2 < 2; ++p2) {
                         const int ch = 32 * tn + 8 * (2 * p2 + g);
-                        if (a.dx_accumulate) oldw[p2] = *(const u32x4_t*)(px + ch * 2);
+                        if (a.dx_accumulate) oldw[p2] = BTS_CHAIN_BATCH_DX ? oldall[tn][p2] : *(const u32x4_t*)(px + ch * 2);
                         // the ELU output the fold needs is the layer-0 input fragment this lane already holds: natural K order puts
                         // channels 16 s + 8 g + 0..7 in in.v[s], and after the permlane swap the lane owns exactly channels
                         // 32 tn + 8 (2 p2 + g) + 0..7 = fragment s = 2 tn + p2 (r5: was a second 16-byte read of x per 8 channels)
@@ -747,7 +803,11 @@ struct BwdLayerF {
                         float v = red[idx];
 #pragma unroll
                         for (int w2 = 1; w2 < NW; ++w2) v += red[w2 * 1024 + idx];
+#ifdef BTS_CHAIN_DIAG_NOATOMIC          // timing-only diagnostic build (tools/build_chain_candidates.sh): what the atomics cost
+                        dst[(size_t)co * ld + ci] = v;
+#else
                         atomicAdd(dst + (size_t)co * ld + ci, v);
+#endif
                     }
                 }
             }
@@ -787,6 +847,9 @@ __global__ __launch_bounds__(64 * NW, 1) void lpg_chain_bwd_f32_kernel(const Cha
         t.lane = lane; t.cl = cl; t.g = g; t.max_depth = a.max_depth;
         Act<F32>::Regs<C0> in;
         load_input_f32<C0>(a.x, (size_t)t.cell, a.x_stride, t.ok, g, in);
+#if BTS_CHAIN_PRE_G
+        prefetch_gout<KUP>(t);                             // head_bwd reads t.gpre
+#endif
         f32x16_t dA[TN0];
         BwdLayerF<C0, NOUT, KUP, 0, NTOT>::run(in, wf, wt, scr, t, dw, dA);
         if (t.ok) {                                        // dx: 4 consecutive channels per accumulator quad = one 16-byte access

@@ -436,8 +436,9 @@ def test_decoder_densenet121_widths_c1_shape_vs_oracle():
             bad["feat%d" % i] = e
     assert not bad, bad
     dec.eval()
+    Pe = {k: v.detach().cpu() for k, v in dec.state_dict().items()}        # running statistics as the train step above left them
     with torch.no_grad():
-        ref_e, _ = O.decoder_forward(P, feats, focal, 10.0, "nyu", False)
+        ref_e, _ = O.decoder_forward(Pe, feats, focal, 10.0, "nyu", False)
         out_e = dec([f.to(DEV) for f in feats], focal.to(DEV))
     for o, r in zip(out_e, ref_e):
         assert rel(o.cpu(), r) < 1e-4

@@ -110,9 +110,11 @@ def test_profiler_labels_follow_dispatch():
     assert conv._fwd_kernel(bf, 32, False) == "conv_igemm_dma<bf16,32x256>"
     assert conv._wgrad_kernel(bf, 1, True, False, 8, 352, 1216) == "conv_wgrad_c1<bf16>"
     assert conv._wgrad_kernel(bf, 32, True, False, 8, 352, 1216) == "conv_wgrad_halo_tr<bf16>"
-    assert conv._wgrad_kernel(bf, 32, True, True, 8, 176, 608) == "conv_wgrad_halo_up<bf16>"
+    assert conv._wgrad_kernel(bf, 32, True, True, 8, 176, 608) == "conv_wgrad_halo_tr_up<bf16>"      # upconv1 (r6: transposing reads)
+    assert conv._wgrad_kernel(bf, 16, True, True, 8, 176, 608) == "conv_wgrad_halo_up<bf16>"         # other widths keep the scatter kernel
     assert conv._wgrad_kernel(bf, 64, True, False, 8, 176, 608) == "conv_wgrad_halo_tr<bf16>"          # conv2: LDS-halo tile + transposing reads
-    assert conv._wgrad_kernel(bf, 64, True, True, 8, 88, 304) == "conv_wgrad_ring<bf16,64x256>"        # upconv2: 64-co ring form
+    assert conv._wgrad_kernel(bf, 64, True, True, 8, 88, 304) == "conv_wgrad_halo_tr_up<bf16>"         # upconv2 (r6; was the 64-co ring form)
+    assert conv._wgrad_kernel(bf, 64, True, True, 1, 32, 64) == "conv_wgrad_ring<bf16,64x256>"         # small map: ring form
     assert conv._wgrad_kernel(bf, 128, True, False, 8, 88, 304, 9 * 232) == "conv_wgrad_halo_tr<bf16>"   # conv3: two 64-channel output tiles
     assert conv._wgrad_kernel(bf, 256, True, False, 8, 44, 152, 9 * 448) == "conv_wgrad_ring<bf16,128x256>"   # conv4: 240 tiles, stays
     assert conv._wgrad_kernel(f32, 32, True, False, 8, 352, 1216) == "conv_wgrad<f32,32x128k4>"
