@@ -325,6 +325,62 @@ __device__ __forceinline__ void store_block32_plain_bf16(const ConvK& a, size_t 
         *(u32x4_t*)((uint16_t*)a.y + opix * a.y_stride + cb + 8 * (2 * p + fk)) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
     }
 }
+// The read-modify-write form in two halves (r6): the old values / ELU outputs of a block are REQUESTED (rmw_request: global loads from
+// inline asm, so that hipcc does not put its own s_waitcnt vmcnt(0) in front of their first use) and consumed later
+// (store_block32_rmw_bf16_from) -- the caller retires them with a counted vmcnt wait of its own and then passes the registers through
+// rmw_landed().  A persistent tile loop requests them BEFORE the tile's MFMAs: an epilogue that loads, waits and stores exposes one full
+// memory round trip per tile to a workgroup that runs in lock step (conv_halo: one workgroup per CU, one barrier per tile).
+template <bool ACC, bool FOLD>
+__device__ __forceinline__ void rmw_request(const ConvK& a, size_t opix, int cb, int fk, u32x4_t (&oldw)[2], u32x4_t (&yw)[2]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int co = cb + 8 * (2 * p + fk);
+        if (ACC) {
+            const uint16_t* q = (const uint16_t*)a.y + opix * a.y_stride + co;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(oldw[p]) : "v"(q) : "memory");
+        }
+        if (FOLD) {
+            const uint16_t* q = (const uint16_t*)a.fold_y + opix * (size_t)a.fold_stride + co;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(yw[p]) : "v"(q) : "memory");
+        }
+    }
+}
+template <bool ACC, bool FOLD>
+__device__ __forceinline__ void rmw_landed(u32x4_t (&oldw)[2], u32x4_t (&yw)[2]) {      // behind the caller's s_waitcnt: pins the order
+    if (ACC) asm volatile("" : "+v"(oldw[0]), "+v"(oldw[1]));
+    if (FOLD) asm volatile("" : "+v"(yw[0]), "+v"(yw[1]));
+}
+template <bool ACC, bool FOLD>
+__device__ __forceinline__ void store_block32_rmw_bf16_from(const ConvK& a, size_t opix, int cb, int fk, float (&v)[16],
+                                                            const u32x4_t (&oldw)[2], const u32x4_t (&yw)[2]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 * p + e]), __float_as_uint(v[8 * p + 4 + e]), false, false);
+            v[8 * p + e] = __uint_as_float(r[0]);
+            v[8 * p + 4 + e] = __uint_as_float(r[1]);
+        }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = v[8 * p + e];
+        if (ACC) {
+            float o[8];
+            BF16::unpack(oldw[p], o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] += o[e];
+        }
+        if (FOLD) {
+            float y[8];
+            BF16::unpack(yw[p], y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] *= elu_dfac(y[e]);
+        }
+        *(u32x4_t*)((uint16_t*)a.y + opix * a.y_stride + cb + 8 * (2 * p + fk)) = BF16::pack(t);
+    }
+}
 template <bool ACC, bool FOLD>
 __device__ __forceinline__ void store_block32_rmw_bf16(const ConvK& a, size_t opix, int cb, int fk, float (&v)[16]) {
     u32x4_t oldw[2], yw[2];

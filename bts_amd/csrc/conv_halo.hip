@@ -8,6 +8,10 @@
 #include "common.h"
 #include "conv_common.h"
 
+#ifndef BTS_HALO_STAGGER
+#define BTS_HALO_STAGGER 1      // 0: every wave runs its epilogue behind the tile barrier (the A side of the r6 A/B build)
+#endif
+
 namespace bts_conv {
 namespace {
 
@@ -40,7 +44,10 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
     constexpr int PR_PAD = (PR + RP - 1) / RP * RP;
     constexpr int WR_PAD = (WR_ROWS + RP - 1) / RP * RP;
     constexpr int NPB = PERSIST ? 2 : 1;                        // patch buffers
-    __shared__ __attribute__((aligned(16))) char smem[(NPB * PR_PAD + WR_PAD) * 128];
+    // the register-weight persistent form (below) runs THREE patch buffers; its weights pass through the third one on their way to registers
+    constexpr int RW3 = (PERSIST && NT <= 9 && NG == 1 && WR_PAD <= PR_PAD) ? 3 * PR_PAD : 0;
+    constexpr int SM_ROWS = RW3 > NPB * PR_PAD + WR_PAD ? RW3 : NPB * PR_PAD + WR_PAD;
+    __shared__ __attribute__((aligned(16))) char smem[SM_ROWS * 128];
     char* sW = smem + NPB * PR_PAD * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sP + (pass * RP + wave * 8) * 128), 16, 0, 0);
         }
     };
-    auto dma_weights = [&](int cc) {      // row = tap*32 + co
+    auto dma_weights = [&](int cc, char* sWd) {      // row = tap*32 + co
         const int cv = cc * 8 + vec;
         const bool kok = cv < a.KV;
 #pragma unroll
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
             const int t = r >> 5, co = co_tile * 32 + (r & 31);
             const char* src = zero;
             if (kok && r < WR_ROWS && co < a.Cout) src = a.w + (((size_t)co * a.Ttot + t) * a.Ktot + (size_t)cv * VEC) * ES;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sW + (pass * RP + wave * 8) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sWd + (pass * RP + wave * 8) * 128), 16, 0, 0);
         }
     };
     // nks: k-steps of this channel chunk that hold real channels (2 vectors each); the rest of the 128-byte row is zero
@@ -148,8 +155,10 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
         constexpr int NQ = TPG * NKS;
         constexpr int D = 2;                                      // fragment pairs in flight ahead of the MFMA that consumes them
         if constexpr (!FULLTAB) {
-            // 16-tap sub-pixel variants (4 accumulators): the hand-placed form below costs them ~60 more registers than they
-            // have (spills); they keep compiler-scheduled loads, straight-line in the k-step count
+            // 16-tap sub-pixel variants (4 accumulators): compiler-scheduled loads, straight-line in the k-step count.  (r6: a hand-
+            // placed read-ahead like the 9-tap form's -- patch row re-derived per read from the wave-uniform tap shift, weight row as an
+            // immediate, four pairs in flight, no spills -- measured 105 -> 109 us on upconv1's forward and 108 -> 110 on upconv2's,
+            // gpurun r06 calls 5 / 6: with eight waves on two 1-KiB reads per MFMA the LDS pipe is the limiter, not the read latency.)
             int lo = 0;
             asm volatile("" : "+v"(lo));          // keeps the 64 + 64 fragment addresses out of LICM's hands (registers)
 #pragma unroll
@@ -303,20 +312,36 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
         // the patch DMA in plain launches -- changes nothing, 0-1 % on every layer: the store latency is not what the loop waits for.)
         if constexpr (FULLTAB && NG == 1) {
             if (nks_all <= (DUAL ? 2 : 3)) {
-                // same pipeline as below (see there), with the weight fragments lifted into registers behind the first barrier
+                // Weight fragments in registers, THREE patch buffers (r6).  With two buffers a CU had one tile's patch (~22 KiB of real
+                // input) in flight while it computed the previous one: by Little's law ~22 KiB x 256 CUs per ~1.5 us of loaded memory
+                // latency = 3.7 TB/s, which is what conv1's forward measured (3.76).  The weights pass through buffer 2 on their way to
+                // the registers, so the third buffer costs no LDS beyond the 144 KiB; patch i+2 is requested at the TOP of iteration i
+                // -- behind the requests for tile i's read-modify-write operands, which therefore arrive under the tile's MFMAs
+                // instead of being awaited in its epilogue -- and awaited at the bottom of iteration i+1:
+                //
+                //     iteration i:  request old / ELU-output values of tile i | DMA patch i+2 -> buffer (i+2) % 3 | MFMAs of tile i
+                //                   | wait: at most the NPASS pieces of patch i+2 outstanding (in-order vmcnt: patch i+1, the requested
+                //                   values and the stores of tile i-1 are older) | s_barrier | stores of tile i
+                //
+                // The barrier publishes patch i+1 and frees buffer i % 3, which patch i+3 is written to in the next iteration.
                 auto run_tiles = [&](auto nks_c) {
                     constexpr int NKS = decltype(nks_c)::value;
-                    dma_weights(0);
+                    // (DUAL launches keep the load-in-epilogue form for their read-modify-write variants: 144 weight-fragment registers
+                    // leave no room for 16 more without spills; the product's DUAL launch -- conv1's data gradients -- is the first
+                    // writer of both buffers: plain stores)
+                    constexpr bool ACC = !DUAL && (EPI == 2 || EPI == 4), FOLD = !DUAL && (EPI == 3 || EPI == 4), RMW = ACC || FOLD;
+                    constexpr int PB = PR_PAD * 128;
+                    dma_weights(0, smem + 2 * PB);
                     int n, y0, x0;
                     tile_origin(t_begin, n, y0, x0);
                     dma_patch(0, n, y0, x0, smem);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
+                    __builtin_amdgcn_s_barrier();
                     u32x4_t faR[NT][NKS];
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int s2 = 0; s2 < NKS; ++s2) faR[t][s2] = *(const u32x4_t*)(sW + t * 32 * 128 + wA[s2]);
+                        for (int s2 = 0; s2 < NKS; ++s2) faR[t][s2] = *(const u32x4_t*)(smem + 2 * PB + t * 32 * 128 + wA[s2]);
                     u32x4_t faR2[DUAL ? NT : 1][DUAL ? NKS : 1];
                     if constexpr (DUAL) {
                         // w2[co][tap][k] (K contiguous, Ktot elements per tap): this lane's A fragment of (tap, k-step) is the
@@ -331,29 +356,76 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
                                 faR2[t][s2] = v;
                             }
                     }
+                    // The fragments must have LANDED as far as hipcc is concerned before the tile loop starts: a register that a global
+                    // load was still writing at the loop's entry makes it put `s_waitcnt vmcnt(0)` in front of the first MFMA that reads
+                    // it IN EVERY ITERATION (seen in the ISA of the round-4 DUAL kernel), i.e. each tile waited for the patch DMA it had
+                    // just issued.  Passing the values through an empty asm retires them once, here.
+                    if constexpr (DUAL) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int s2 = 0; s2 < NKS; ++s2) asm volatile("" : "+v"(faR2[t][s2]));
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int s2 = 0; s2 < NKS; ++s2) asm volatile("" : "+v"(faR[t][s2]));
                     int n1 = 0, y1 = 0, x1 = 0;
                     if (t_begin + 1 < t_end) {
                         tile_origin(t_begin + 1, n1, y1, x1);
-                        dma_patch(0, n1, y1, x1, smem + PR_PAD * 128);
+                        dma_patch(0, n1, y1, x1, smem + PB);
                     }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every wave has its weight fragments: buffer 2 is free
+                    __builtin_amdgcn_s_barrier();
+                    int cur = 0;                                           // buffer of tile `tile`: (tile - t_begin) % 3
+                    const bool early = BTS_HALO_STAGGER && wave < TH / 2;
                     for (int tile = t_begin; tile < t_end; ++tile) {
-                        const int cur = (tile - t_begin) & 1;
+                        const int oy = y0 + wave, ox = x0 + frow;
+                        const bool inside = oy < a.Hg && ox < a.Wg;
+                        const size_t opix = ((size_t)n * a.Hy + oy) * a.Wy + ox;
+                        u32x4_t oldw[2], yw[2];
+                        if constexpr (RMW) {
+                            if (inside) rmw_request<ACC, FOLD>(a, opix, co_tile * 32, fk, oldw, yw);
+                        }
+                        const bool more = tile + 2 < t_end;
+                        int n2 = 0, y2 = 0, x2 = 0;
+                        const int nxt2 = cur == 0 ? 2 : cur - 1;           // (cur + 2) % 3
+                        if (more) {
+                            tile_origin(tile + 2, n2, y2, x2);
+                            dma_patch(0, n2, y2, x2, smem + nxt2 * PB);
+                        }
                         f32x16_t acc[NG], acc2;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc2[r] = 0.f; }
-                        compute_rw(smem + cur * PR_PAD * 128, acc[0], acc2, faR, faR2, nks_c);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __syncthreads();
-                        int n2 = 0, y2 = 0, x2 = 0;
-                        const bool more = tile + 2 < t_end;
-                        if (more) tile_origin(tile + 2, n2, y2, x2);
-                        const bool reads_mem = a.accumulate || a.fold_y || (DUAL && a.accumulate2);
-                        if (more && !reads_mem) dma_patch(0, n2, y2, x2, smem + cur * PR_PAD * 128);
-                        epilogue(acc, n, y0, x0);
-                        if constexpr (DUAL) epilogue2(acc2, n, y0, x0);
-                        if (more && reads_mem) dma_patch(0, n2, y2, x2, smem + cur * PR_PAD * 128);
+                        compute_rw(smem + cur * PB, acc[0], acc2, faR, faR2, nks_c);
+                        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPASS) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        auto tile_epilogue = [&]() {
+                            if constexpr (RMW) {
+                                if (inside) {
+                                    rmw_landed<ACC, FOLD>(oldw, yw);
+                                    float v[16];
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) v[r] = acc[0][r];
+                                    store_block32_rmw_bf16_from<ACC, FOLD>(a, opix, co_tile * 32, fk, v, oldw, yw);
+                                }
+                            } else {
+                                epilogue(acc, n, y0, x0);
+                            }
+                            if constexpr (DUAL) epilogue2(acc2, n, y0, x0);
+                        };
+                        // STAGGERED epilogue (r6): the barrier aligns all eight waves, so a tile used to cost an LDS / MFMA phase
+                        // (every wave in its k-steps) plus a VALU phase (every wave in ELU + pack + stores + the next DMA's address
+                        // arithmetic) back to back -- conv1's forward: ~2 000 + ~3 500 of its ~6 000 cycles per tile.  The epilogue
+                        // touches no LDS, so it may sit on either side of the barrier: waves 0-3 run it BEFORE, waves 4-7 AFTER
+                        // (wave w and w + 4 share a SIMD), and between two barriers one wave of a SIMD is in its VALU phase while
+                        // the other one is in its k-steps.
+                        if (early) tile_epilogue();
+                        __builtin_amdgcn_s_barrier();
+                        if (!early) tile_epilogue();
                         n = n1; y0 = y1; x0 = x1;
                         n1 = n2; y1 = y2; x1 = x2;
+                        cur = cur == 2 ? 0 : cur + 1;
                     }
                 };
                 if (nks_all == 1) run_tiles(std::integral_constant<int, 1>());
@@ -370,7 +442,7 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
         // TOP of the iteration, i.e. directly behind the previous tile's stores: their full write latency was exposed on every
         // tile (SQ counters: waves parked 52 % of their cycles).  Accumulating epilogues read the old value, and hipcc drains
         // vmcnt(0) before using it, so there the refill is issued after the epilogue instead.
-        dma_weights(0);
+        dma_weights(0, sW);
         int n, y0, x0;
         tile_origin(t_begin, n, y0, x0);
         dma_patch(0, n, y0, x0, smem);
@@ -390,13 +462,18 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
                 for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
             compute(smem + cur * PR_PAD * 128, acc, nks_all);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // staggered epilogue (see the register-weight form above): launches whose epilogue only STORES run it before the barrier
+            // in waves 0-3 and behind it (and behind the refill's issue) in waves 4-7
+            const bool reads_mem = a.accumulate || a.fold_y;
+            const bool early = BTS_HALO_STAGGER && EPI != 0 && !reads_mem && wave < TH / 2;
+            if (early) epilogue(acc, n, y0, x0);
             __syncthreads();                         // patch tile+1 landed everywhere; buffer `cur` is free
             int n2 = 0, y2 = 0, x2 = 0;
             const bool more = tile + 2 < t_end;
             if (more) tile_origin(tile + 2, n2, y2, x2);
-            if (more && !(a.accumulate || a.fold_y)) dma_patch(0, n2, y2, x2, smem + cur * PR_PAD * 128);
-            epilogue(acc, n, y0, x0);
-            if (more && (a.accumulate || a.fold_y)) dma_patch(0, n2, y2, x2, smem + cur * PR_PAD * 128);   // (the fold reads memory too)
+            if (more && !reads_mem) dma_patch(0, n2, y2, x2, smem + cur * PR_PAD * 128);
+            if (!early) epilogue(acc, n, y0, x0);
+            if (more && reads_mem) dma_patch(0, n2, y2, x2, smem + cur * PR_PAD * 128);   // (the fold reads memory too)
             n = n1; y0 = y1; x0 = x1;
             n1 = n2; y1 = y2; x1 = x2;
         }
@@ -410,7 +487,7 @@ __global__ __launch_bounds__(64 * TH) void conv_halo(const ConvK a) {
             for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
         for (int cc = 0; cc < nchunks; ++cc) {
             dma_patch(cc, n, y0, x0, smem);
-            dma_weights(cc);
+            dma_weights(cc, sW);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             compute(smem, acc, (min(a.KV - cc * 8, 8) + 1) >> 1);

@@ -415,7 +415,7 @@ class DecoderRun:
         out = torch.empty((N, H, W, ctot), dtype=self.dtype, device=dev)
         out2 = torch.empty_like(out) if relu_copy else None
         ops.bn_apply([s.t for s in segs], stats, g, b, eps, relu, out, out2, BN_MOMENTUM if train else 0.0,
-                     rm if train else None, rv if train else None)
+                     rm if train else None, rv if train else None, tag=prefix)
         if train:
             nbt = P.get(prefix + ".num_batches_tracked")
             if nbt is not None:
@@ -439,7 +439,7 @@ class DecoderRun:
                     if accs[0]:
                         raise BtsAmdError("bn_cat: ELU-folded input of %s has another consumer" % prefix)
                     segs[0].g_is_dz = True
-                db, dg = ops.bn_bwd_ms(y.g, [s.t for s in segs], [s.g for s in segs], accs, stats, g, b, eps, relu, train, fold)
+                db, dg = ops.bn_bwd_ms(y.g, [s.t for s in segs], [s.g for s in segs], accs, stats, g, b, eps, relu, train, fold, tag=prefix)
                 self.grads[prefix + ".weight"] = dg
                 self.grads[prefix + ".bias"] = db
             self.tape.append(bwd)

@@ -367,7 +367,7 @@ def _bn_desc(xs, stats, gamma, beta, eps, relu):
     return d
 
 
-def bn_apply(xs, stats, gamma, beta, eps, relu, out, out2=None, momentum=0.0, running_mean=None, running_var=None):
+def bn_apply(xs, stats, gamma, beta, eps, relu, out, out2=None, momentum=0.0, running_mean=None, running_var=None, tag=None):
     """BatchNorm(+ReLU) of the channel concatenation of `xs` (NHWC tensors, same pixels) into `out` in ONE launch; `stats` holds
     each tensor's (mean, var).  out2 (optional) receives relu(out).  running_*: train-mode update of the [sum C] buffers."""
     if len(xs) > _lib.BN_MAX_SEG:
@@ -382,12 +382,12 @@ def bn_apply(xs, stats, gamma, beta, eps, relu, out, out2=None, momentum=0.0, ru
         d.y2, d.y2_stride = out2.data_ptr(), pix_stride(out2)
     if profiler.ACTIVE is not None:
         ctot = sum(x.shape[3] for x in xs)
-        profiler.note("bn_apply", "hbm", npix(xs[0]) * ctot * xs[0].element_size() * (3 if out2 is not None else 2))
+        profiler.note("bn_apply", "hbm", npix(xs[0]) * ctot * xs[0].element_size() * (3 if out2 is not None else 2), tag)
     call("bts_bn_apply", C.byref(d), stream_ptr())
     return out
 
 
-def bn_bwd_ms(dy, xs, dxs, accs, stats, gamma, beta, eps, relu, use_batch_stats, elu_x=False):
+def bn_bwd_ms(dy, xs, dxs, accs, stats, gamma, beta, eps, relu, use_batch_stats, elu_x=False, tag=None):
     """Backward of bn_apply: dy = gradient of the normalised concatenation; dxs[i] (+)= gradient of xs[i]; returns
     (dbeta, dgamma) over the concatenated channels.  elu_x: see include/bts_amd.h (ELU derivative of the producer folded in)."""
     d = _bn_desc(xs, stats, gamma, beta, eps, relu)
@@ -401,7 +401,7 @@ def bn_bwd_ms(dy, xs, dxs, accs, stats, gamma, beta, eps, relu, use_batch_stats,
     sums = torch.empty((2, ctot), dtype=torch.float32, device=dy.device)
     if profiler.ACTIVE is not None:      # reduction pass: dy + x; apply pass: dy + x read, dx written (+ read when accumulating)
         es = xs[0].element_size()
-        profiler.note("bn_bwd", "hbm", npix(xs[0]) * es * sum(x.shape[3] * (6 if a else 5) for x, a in zip(xs, accs)))
+        profiler.note("bn_bwd", "hbm", npix(xs[0]) * es * sum(x.shape[3] * (6 if a else 5) for x, a in zip(xs, accs)), tag)
     call("bts_bn_bwd", C.byref(d), _p(ws), _p(sums), stream_ptr())
     return sums[0], sums[1]
 

@@ -4,10 +4,12 @@ run_to() {
     local t=$1; shift
     setsid "$@" &
     local pid=$!
-    ( sleep "$t"; kill -KILL -- -"$pid" 2>/dev/null ) &
+    # the watchdog must not hold the caller's stdout / stderr: in `run_to 900 cmd | tail` its orphaned `sleep` would keep the pipe open
+    # (and the gpurun call running, and charged) for the full limit after cmd has long finished -- two calls of round 6 lost 40 min each
+    ( sleep "$t"; kill -KILL -- -"$pid" 2>/dev/null ) > /dev/null 2>&1 < /dev/null &
     local w=$!
     wait "$pid"; local rc=$?
-    kill "$w" 2>/dev/null; wait "$w" 2>/dev/null
+    pkill -P "$w" 2>/dev/null; kill "$w" 2>/dev/null; wait "$w" 2>/dev/null
     kill -KILL -- -"$pid" 2>/dev/null      # stragglers of a finished command
     return $rc
 }

@@ -12,6 +12,7 @@ and the executed / algorithmic FLOP ratio (tile padding: busy cycles / 32 x 3276
 Families are the ones bench.py / tools/pmc_traffic.py use (pmc_traffic.family)."""
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
 
@@ -64,8 +65,8 @@ def main():
                 row["event_timed_us_per_launch"] = round(us, 1)
                 row["mfma_util_at_2.4GHz"] = round(busy / (1024 * us * 1e-6 * 2.4e9), 4)
                 row["executed_over_algorithmic_flops"] = round(busy / 32 * 32768 / flops, 3)
-    table["_meta"] = {"library_md5": md5, "source": "rocprofv3 --pmc (one SQ pass) --kernel-trace of bench.py --graph 0, BTS_CONV_WIDE=0 "
-                      "(conv_halo_wide aborts counter passes: the wide 3x3 layers run on conv_igemm_dma in this pass)"}
+    table["_meta"] = {"library_md5": md5, "source": "rocprofv3 --pmc (one SQ pass) --kernel-trace of bench.py --graph 0 (kernel mix: PMC_ENV of tools/final_protocol.sh = '%s'; "
+                      "empty = the default switches of the timed step)" % os.environ.get("PMC_ENV", "")}
     with open(out, "w") as fh:
         json.dump(table, fh, indent=1)
     for f, row in table.items():

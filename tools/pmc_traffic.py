@@ -18,6 +18,7 @@ Infinity-Cache hits are counted by both, so this is fabric-side traffic, an uppe
 """
 import csv
 import json
+import os
 import re
 import sys
 from collections import defaultdict
@@ -127,9 +128,12 @@ def main():
         if fam in alg:
             table[fam]["alg_bytes_per_launch"] = round(alg[fam])
             table[fam]["traffic_over_algorithmic"] = round((rd + wr) / alg[fam], 2)
-    table["_meta"] = {"library_md5": md5, "config": "both passes with BTS_CONV_WIDE=0 BTS_RES=0 (rocprofv3 aborts the FETCH_SIZE pass at the first dispatch of "
-                      "conv_halo_wide or conv_igemm_res): the wide 3x3 layers and the short-K 1x1 launches run on conv_igemm_dma here, so that family covers more "
-                      "launches per step than in the timed step",
+    mix = os.environ.get("PMC_ENV", "").strip()
+    table["_meta"] = {"library_md5": md5,
+                      "config": ("both passes with %s: kernels that rocprofv3 aborted on in rounds 3-5 are switched off, so conv_igemm_dma covers more "
+                                 "launches per step than in the timed step" % mix) if mix else
+                                "default switches: both passes on the kernel mix of the timed step (conv_halo_wide and conv_igemm_res dispatched; "
+                                "rounds 3-5 needed BTS_CONV_WIDE=0 BTS_RES=0 here)",
                       "note": "every figure is per C-ABI CALL (bench.py's unit): bn_bwd = reduction + final + apply kernels of one call, "
                       "bn_stats = partial + final -- their kernels' counters are summed per call"}
     with open(out, "w") as f:
