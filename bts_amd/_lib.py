@@ -83,6 +83,25 @@ class BnDesc(C.Structure):
                 ("y", C.c_void_p), ("y_stride", C.c_int32), ("elu_x", C.c_int32), ("y2", C.c_void_p), ("y2_stride", C.c_int32)]
 
 
+BN_MAX_MULTI = 4
+BN_MULTI_TENSORS = 3
+
+
+class BnContrib(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("dy_stride", C.c_int32), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("dbeta", C.c_void_p), ("dgamma", C.c_void_p)]
+
+
+class BnMultiTensor(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_stride", C.c_int32), ("C", C.c_int32), ("mean", C.c_void_p), ("var", C.c_void_p),
+                ("dx", C.c_void_p), ("dx_stride", C.c_int32), ("accumulate", C.c_int32), ("c", BnContrib * BN_MAX_MULTI)]
+
+
+class BnMultiDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("nt", C.c_int32), ("relu", C.c_int32), ("M", C.c_int64),
+                ("eps", C.c_float), ("use_batch_stats", C.c_int32), ("t", BnMultiTensor * BN_MULTI_TENSORS)]
+
+
 _i, _l, _f, _p = C.c_int, C.c_long, C.c_float, C.c_void_p
 
 # name -> argtypes (restype is int unless listed in _LONG_RET); mirrors include/bts_amd.h exactly
@@ -131,12 +150,15 @@ SIGNATURES = {
     "bts_bn_apply": [C.POINTER(BnDesc), _p],
     "bts_bn_bwd_workspace_bytes": [C.POINTER(BnDesc)],
     "bts_bn_bwd": [C.POINTER(BnDesc), _p, _p, _p],
+    "bts_bn_bwd_multi_workspace_bytes": [C.POINTER(BnMultiDesc)],
+    "bts_bn_bwd_multi": [C.POINTER(BnMultiDesc), _p, _p],
     "bts_act_bwd": [_p, _i, _i, _p, _i, _i, _p, _i, _i, _l, _i, _i, _f, _p, _l, _i, _p],
     "bts_add_to": [_p, _i, _i, _p, _i, _i, _l, _i, _i, _p],
     "bts_adamw_step": [_p, _p, _p, _p, _p, _i, _l, _f, _f, _f, _f, _f, _f, _f, _p, _p],
     "bts_adamw_advance": [_p, _i, _p],
 }
-_LONG_RET = {"bts_silog_workspace_bytes", "bts_bn_stats_workspace_bytes", "bts_eval_workspace_bytes", "bts_bn_bwd_workspace_bytes"}
+_LONG_RET = {"bts_silog_workspace_bytes", "bts_bn_stats_workspace_bytes", "bts_eval_workspace_bytes", "bts_bn_bwd_workspace_bytes",
+             "bts_bn_bwd_multi_workspace_bytes"}
 _NO_CHECK = _LONG_RET | {"bts_abi_version", "bts_current_device"}
 
 _lib = None

@@ -1046,6 +1046,321 @@ extern "C" int bts_bn_bwd(const bts_bn_desc_t* d, void* workspace, float* sums, 
     return BTS_OK;
 }
 
+// ---- several BatchNorms over one shared input, backward (include/bts_amd.h: bts_bn_bwd_multi) ------------------------------------
+// A thread owns FOUR channels, not a 16-byte vector (bf16: 8-byte accesses): with up to four BatchNorms the per-channel state is
+// 2 x NB accumulators + 2 x NB (gamma, beta) + mean / invstd, which at eight channels took all 256 registers (first build: two waves
+// per SIMD, 1 TB/s); four channels and U = 4 loads in flight per stream keep it at 100-130.
+template <typename T> struct Quad;
+template <> struct Quad<F32> {
+    typedef u32x4_t raw;
+    static constexpr int kBytes = 16;
+    __device__ static __forceinline__ void unpack(const raw& v, float* f) { F32::unpack(v, f); }
+    __device__ static __forceinline__ raw pack(const float* f) { return F32::pack(f); }
+};
+template <> struct Quad<BF16> {
+    typedef u32x2_t raw;
+    static constexpr int kBytes = 8;
+    __device__ static __forceinline__ void unpack(const raw& v, float* f) {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    }
+    __device__ static __forceinline__ raw pack(const float* f) { raw v; v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]); return v; }
+};
+template <typename R>
+__device__ __forceinline__ R ldq(const char* base, long p, size_t step) { return *(const R*)(base + (size_t)p * step); }
+
+struct BnMultiT {
+    const char* x; char* dx;
+    const float* mean; const float* var;
+    int xs, dxs, CQ, acc, by0, cbase;          // CQ: channel quads; by0: first blockIdx.x; cbase: first column inside a BatchNorm's block
+    const char* dy[BTS_BN_MAX_MULTI];
+    int dys[BTS_BN_MAX_MULTI];
+    const float* gamma[BTS_BN_MAX_MULTI];
+    const float* beta[BTS_BN_MAX_MULTI];
+    float* dbeta[BTS_BN_MAX_MULTI];
+    float* dgamma[BTS_BN_MAX_MULTI];
+};
+struct BnMultiK {
+    BnMultiT t[BTS_BN_MULTI_TENSORS];
+    int nt, bxl, use_batch, ctot;              // ctot: columns of one BatchNorm's block of a workspace row (all tensors, padded)
+    long M;
+    float eps;
+};
+// field F of the tensor this block works on (ti is wave-uniform; per-field selects: a dynamic index into the by-value argument would
+// copy it through scratch)
+#define BN_MT_(F) (ti == 2 ? k.t[2].F : (ti == 1 ? k.t[1].F : k.t[0].F))
+static_assert(BTS_BN_MULTI_TENSORS == 3, "BN_MT_ selects among three tensors");
+
+// pass 1: per workgroup row, NB pairs of partial sums per channel: ws[row][2][NB * ctot], column b * ctot + cbase + c
+template <typename T, int U, int NB, bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_multi_partial_kernel(const BnMultiK k, float* __restrict__ ws) {
+    typedef Quad<T> Q;
+    typedef typename Q::raw R;
+    const int ti = (k.nt > 2 && (int)blockIdx.x >= k.t[2].by0) ? 2 : ((k.nt > 1 && (int)blockIdx.x >= k.t[1].by0) ? 1 : 0);
+    const int bx = 1 << k.bxl, tx = threadIdx.x & (bx - 1), ty = threadIdx.x >> k.bxl, by = 256 >> k.bxl;
+    const int cq = ((int)blockIdx.x - BN_MT_(by0)) * bx + tx, CQ = BN_MT_(CQ);
+    long p = (long)blockIdx.y * by + ty;
+    const long ps = (long)gridDim.y * by;
+    float a[NB][4], b[NB][4];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[n][e] = b[n][e] = 0.f;
+    if (cq < CQ) {
+        float mu[4], is[4], g[NB][4], be[NB][4];
+        const float* mean = BN_MT_(mean);
+        const float* var = BN_MT_(var);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { mu[e] = mean[cq * 4 + e]; is[e] = var[cq * 4 + e]; }
+        const char* db[NB];
+        size_t dst[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const float* gp = BN_MT_(gamma[n]);
+            const float* bp = BN_MT_(beta[n]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { g[n][e] = gp[cq * 4 + e]; be[n][e] = bp[cq * 4 + e]; }
+            db[n] = BN_MT_(dy[n]) + (size_t)cq * Q::kBytes;
+            dst[n] = (size_t)BN_MT_(dys[n]) * T::kBytes;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) is[e] = 1.f / sqrtf(is[e] + k.eps);
+        const char* xb = BN_MT_(x) + (size_t)cq * Q::kBytes;
+        const size_t xst = (size_t)BN_MT_(xs) * T::kBytes;
+        auto one = [&](const R& vx, const R (&vd)[NB]) {
+            float fx[4];
+            Q::unpack(vx, fx);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fx[e] = (fx[e] - mu[e]) * is[e];      // xhat: bn_bwd_partial_ms_kernel's arithmetic
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                float fd[4];
+                Q::unpack(vd[n], fd);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d = fd[e];
+                    if (RELU) d = (fx[e] * g[n][e] + be[n][e] > 0.f) ? d : 0.f;
+                    a[n][e] += d; b[n][e] += d * fx[e];
+                }
+            }
+        };
+        for (; p + (U - 1) * ps < k.M; p += U * ps) {
+            R vx[U], vd[U][NB];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                vx[u] = ldq<R>(xb, p + u * ps, xst);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) vd[u][n] = ldq<R>(db[n], p + u * ps, dst[n]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) one(vx[u], vd[u]);
+        }
+        for (; p < k.M; p += ps) {
+            R vd[NB];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) vd[n] = ldq<R>(db[n], p, dst[n]);
+            one(ldq<R>(xb, p, xst), vd);
+        }
+    }
+    // block reduction over the pixel rows (ty) in a fixed order, one BatchNorm at a time through one LDS scratch
+    __shared__ float red[256][9];
+    const int col0 = BN_MT_(cbase) + cq * 4;
+    const size_t rowlen = (size_t)NB * k.ctot;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        __syncthreads();                                        // the scratch is reused (and read by ty == 0 below)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = a[n][e]; red[threadIdx.x][4 + e] = b[n][e]; }
+        __syncthreads();
+        if (ty == 0 && cq < CQ) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sa = 0.f, sb = 0.f;
+                for (int t = 0; t < by; ++t) { sa += red[t * bx + tx][e]; sb += red[t * bx + tx][4 + e]; }
+                ws[((size_t)blockIdx.y * 2 + 0) * rowlen + (size_t)n * k.ctot + col0 + e] = sa;
+                ws[((size_t)blockIdx.y * 2 + 1) * rowlen + (size_t)n * k.ctot + col0 + e] = sb;
+            }
+        }
+    }
+}
+
+// pass 2: sums = [2][NB * ctot] (pass-1 rows summed).  Block row 0 also writes dbeta_b / dgamma_b.
+template <typename T, int U, int NB, bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_multi_apply_kernel(const BnMultiK k, const float* __restrict__ sums) {
+    typedef Quad<T> Q;
+    typedef typename Q::raw R;
+    const int ti = (k.nt > 2 && (int)blockIdx.x >= k.t[2].by0) ? 2 : ((k.nt > 1 && (int)blockIdx.x >= k.t[1].by0) ? 1 : 0);
+    const int bx = 1 << k.bxl, tx = threadIdx.x & (bx - 1), ty = threadIdx.x >> k.bxl, by = 256 >> k.bxl;
+    const int cq = ((int)blockIdx.x - BN_MT_(by0)) * bx + tx;
+    if (cq >= BN_MT_(CQ)) return;
+    const bool acc = BN_MT_(acc) != 0;
+    long p = (long)blockIdx.y * by + ty;
+    const long ps = (long)gridDim.y * by;
+    float mu[4], is[4], g[NB][4], be[NB][4], K0[4], K1[4];
+    const float invM = 1.f / (float)k.M;
+    const float* mean = BN_MT_(mean);
+    const float* var = BN_MT_(var);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { mu[e] = mean[cq * 4 + e]; is[e] = var[cq * 4 + e]; K0[e] = 0.f; K1[e] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) is[e] = 1.f / sqrtf(is[e] + k.eps);
+    const int col0 = BN_MT_(cbase) + cq * 4;
+    const char* db[NB];
+    size_t dst[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const float* gp = BN_MT_(gamma[n]);
+        const float* bp = BN_MT_(beta[n]);
+        float* dbp = BN_MT_(dbeta[n]);
+        float* dgp = BN_MT_(dgamma[n]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = cq * 4 + e;
+            g[n][e] = gp[c]; be[n][e] = bp[c];
+            const float s0 = sums[n * k.ctot + col0 + e], s1 = sums[(NB + n) * k.ctot + col0 + e];
+            if (blockIdx.y == 0 && ty == 0) { dbp[c] = s0; dgp[c] = s1; }
+            // dx = sum_b g_b is (dz_b - s0_b / M - xhat s1_b / M): the two per-channel terms summed over b up front
+            K0[e] += k.use_batch ? g[n][e] * (s0 * invM) : 0.f;
+            K1[e] += k.use_batch ? g[n][e] * (s1 * invM) : 0.f;
+        }
+        db[n] = BN_MT_(dy[n]) + (size_t)cq * Q::kBytes;
+        dst[n] = (size_t)BN_MT_(dys[n]) * T::kBytes;
+    }
+    const char* xb = BN_MT_(x) + (size_t)cq * Q::kBytes;
+    char* ob = BN_MT_(dx) + (size_t)cq * Q::kBytes;
+    const size_t xst = (size_t)BN_MT_(xs) * T::kBytes, ost = (size_t)BN_MT_(dxs) * T::kBytes;
+    auto one = [&](const R& vx, const R (&vd)[NB], const R& vo, long q) {
+        float fx[4], o[4], sum[4];
+        Q::unpack(vx, fx);
+        Q::unpack(vo, o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { fx[e] = (fx[e] - mu[e]) * is[e]; sum[e] = 0.f; }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            float fd[4];
+            Q::unpack(vd[n], fd);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float d = fd[e];
+                if (RELU) d = (fx[e] * g[n][e] + be[n][e] > 0.f) ? d : 0.f;
+                sum[e] += g[n][e] * d;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float r = is[e] * (sum[e] - K0[e] - fx[e] * K1[e]);
+            o[e] = acc ? o[e] + r : r;
+        }
+        *(R*)(ob + (size_t)q * ost) = Q::pack(o);
+    };
+    for (; p + (U - 1) * ps < k.M; p += U * ps) {
+        R vx[U], vd[U][NB], vo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            vx[u] = ldq<R>(xb, p + u * ps, xst);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) vd[u][n] = ldq<R>(db[n], p + u * ps, dst[n]);
+            vo[u] = vx[u];
+            if (acc) vo[u] = ldq<R>(ob, p + u * ps, ost);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(vx[u], vd[u], vo[u], p + u * ps);
+    }
+    for (; p < k.M; p += ps) {
+        R vd[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) vd[n] = ldq<R>(db[n], p, dst[n]);
+        const R vx = ldq<R>(xb, p, xst);
+        one(vx, vd, acc ? ldq<R>(ob, p, ost) : vx, p);
+    }
+}
+#undef BN_MT_
+
+static const int kBnMultiRows = 1024;      // most partial-sum rows of bn_bwd_multi_partial_kernel
+static long bn_multi_ctot(const bts_bn_multi_desc_t* d) {
+    long c = 0;
+    for (int t = 0; t < d->nt; ++t) c += (d->t[t].C + 7) / 8 * 8;
+    return c;
+}
+extern "C" long bts_bn_bwd_multi_workspace_bytes(const bts_bn_multi_desc_t* d) {
+    if (!d || d->n < 1 || d->n > BTS_BN_MAX_MULTI || d->nt < 1 || d->nt > BTS_BN_MULTI_TENSORS) return 0;
+    return ((long)kBnMultiRows + 1) * 2 * d->n * bn_multi_ctot(d) * (long)sizeof(float) + 64;     // partial rows + the summed row
+}
+
+extern "C" int bts_bn_bwd_multi(const bts_bn_multi_desc_t* d, void* workspace, bts_stream_t stream) {
+    BTS_CHECK_ARG(d && workspace && d->n >= 1 && d->n <= BTS_BN_MAX_MULTI && d->nt >= 1 && d->nt <= BTS_BN_MULTI_TENSORS && d->M > 0);
+    BTS_CHECK_ARG(d->dtype == BTS_F32 || d->dtype == BTS_BF16);
+    BTS_CHECK_ARG(((uintptr_t)workspace & 15) == 0);
+    BnMultiK k{};
+    k.nt = d->nt; k.use_batch = d->use_batch_stats; k.M = d->M; k.eps = d->eps;
+    k.ctot = (int)bn_multi_ctot(d);
+    // one lane width for the launch: the largest power of two <= 32 that divides every tensor's quad count (idle lanes otherwise)
+    int bxl = 5;
+    for (int t = 0; t < d->nt; ++t) {
+        BTS_CHECK_ARG(d->t[t].C > 0 && d->t[t].C % 4 == 0);
+        while (bxl > 2 && (d->t[t].C / 4) % (1 << bxl) != 0) --bxl;
+    }
+    k.bxl = bxl;
+    const int bx = 1 << bxl, by = 256 >> bxl;
+    int gy = 0, cbase = 0;
+    for (int t = 0; t < d->nt; ++t) {
+        const bts_bn_multi_tensor_t& s = d->t[t];
+        BTS_CHECK_ARG(s.x && s.dx && s.mean && s.var && vec_ok(d->dtype, s.C, s.x_stride, s.x) && vec_ok(d->dtype, s.C, s.dx_stride, s.dx));
+        BnMultiT& o = k.t[t];
+        o.x = (const char*)s.x; o.dx = (char*)s.dx; o.mean = s.mean; o.var = s.var;
+        o.xs = s.x_stride; o.dxs = s.dx_stride; o.CQ = s.C / 4; o.acc = s.accumulate;
+        o.by0 = gy; o.cbase = cbase;
+        gy += (o.CQ + bx - 1) / bx;
+        cbase += (s.C + 7) / 8 * 8;
+        for (int n = 0; n < d->n; ++n) {
+            const bts_bn_contrib_t& c = s.c[n];
+            BTS_CHECK_ARG(c.dy && c.gamma && c.beta && c.dbeta && c.dgamma && vec_ok(d->dtype, s.C, c.dy_stride, c.dy));
+            BTS_CHECK_ARG(c.dy != s.dx);
+            o.dy[n] = (const char*)c.dy; o.dys[n] = c.dy_stride; o.gamma[n] = c.gamma; o.beta[n] = c.beta;
+            o.dbeta[n] = c.dbeta; o.dgamma[n] = c.dgamma;
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    float* sums = ws + (size_t)kBnMultiRows * 2 * d->n * k.ctot;
+    // pixel rows of blocks: enough workgroups to fill the chip four times over (a 64-channel tensor alone is ONE block column), at
+    // least four pixels per thread, at most `cap` rows
+    auto rows_for = [&](long cap) {
+        long want = (4l * bts_cu_count() * 4 + gy - 1) / gy;
+        const long most = (d->M + 4l * by - 1) / (4l * by);
+        if (want > most) want = most;
+        if (want > cap) want = cap;
+        return (unsigned)(want < 1 ? 1 : want);
+    };
+    // channel blocks on blockIdx.x (dispatched first), pixel rows on blockIdx.y: a BatchNorm's gradient is a channel SLICE of a wider
+    // tensor per input tensor -- 256 of 1152 bytes of a pixel for the 128-channel tensor of the 576-channel concatenation -- and the
+    // blocks that read the neighbouring slices of the same pixels are the other tensors' blocks of the same blockIdx.y: run side by
+    // side they consume whole rows (r6: rows on blockIdx.x measured 2.3 TB/s on the three-tensor launch)
+    const dim3 gp((unsigned)gy, rows_for(kBnMultiRows)), ga((unsigned)gy, rows_for(65535));
+    const int cols = d->n * k.ctot;
+#define LP_(TT, NN, RR) hipLaunchKernelGGL((bn_bwd_multi_partial_kernel<TT, (NN >= 3 ? 2 : 4), NN, RR>), gp, dim3(256), 0, st, k, ws)
+#define LA_(TT, NN, RR) hipLaunchKernelGGL((bn_bwd_multi_apply_kernel<TT, (NN >= 3 ? 2 : 4), NN, RR>), ga, dim3(256), 0, st, k, (const float*)sums)
+#define BOTH_(TT, NN)                                                                                                   \
+    do {                                                                                                                \
+        if (d->relu) LP_(TT, NN, true); else LP_(TT, NN, false);                                                        \
+        launch_stats_final(ws, (int)gp.y, cols, cols, (double)d->M, 1, sums, sums + cols, st);                          \
+        if (d->relu) LA_(TT, NN, true); else LA_(TT, NN, false);                                                        \
+    } while (0)
+#define BYN_(TT)                                                                                                        \
+    do {                                                                                                                \
+        switch (d->n) { case 1: BOTH_(TT, 1); break; case 2: BOTH_(TT, 2); break; case 3: BOTH_(TT, 3); break; default: BOTH_(TT, 4); }   \
+    } while (0)
+    if (d->dtype == BTS_F32) BYN_(F32); else BYN_(BF16);
+#undef BYN_
+#undef BOTH_
+#undef LA_
+#undef LP_
+    BTS_LAUNCH_CHECK();
+    return BTS_OK;
+}
+
 extern "C" int bts_bn_bwd_reduce(const void* dy, int dy_stride, const void* x, int x_stride, int dtype, long M, int C,
                                  const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
                                  void* workspace, float* sums, bts_stream_t stream) {

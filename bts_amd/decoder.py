@@ -30,6 +30,10 @@ EPI_STATS = os.environ.get("BTS_EPI_STATS", "1") != "0"
 # fused recompute backward of the narrow LPG chains; the tests flip this module constant to train the chains layer by layer
 # (the layer-wise path is the checker of the fused one, tests/test_gpu_2_decoder.py)
 FUSED_CHAIN_BWD = True
+# r6: BatchNorms over a channel concatenation (the dense-ASPP first_bn layers) hand the backward of every input tensor to ONE launch
+# per tensor, when all the BatchNorms that normalised it have contributed (DecoderRun._flush_shared_bn); 0 = one bts_bn_bwd per
+# BatchNorm over all of its segments, as rounds 3-5 did (the A side of the A/B, and the checker in tests/test_gpu_2_decoder.py)
+MULTI_BN_BWD = os.environ.get("BTS_BN_MULTI", "1") != "0"
 
 
 def reduction_specs(c_in, c_out, is_final):
@@ -226,6 +230,7 @@ class DecoderRun:
         self.packs = ps
         self.dwp_arena = None
         self.wgrad_pending = []
+        self.bn_shared = {}          # id(Act) -> pending backward contributions of the concatenation BatchNorms that normalised it
 
     # ---- ops -------------------------------------------------------------------------------
     def _use(self, a, can_fold):
@@ -426,8 +431,32 @@ class DecoderRun:
         fold = x_act == ACT_ELU and len(segs) == 1 and firsts[0]
         if x_act != ACT_NONE and len(segs) != 1:
             raise BtsAmdError("bn_cat: x_act is only supported for a single ELU input")
+        # A concatenation BatchNorm in training mode shares each input tensor (and its batch statistics) with the other BatchNorms that
+        # see it: the backward of a tensor waits until the LAST of them (in backward order) has contributed and then runs once
+        # (_flush_shared_bn).  A tensor's producer comes before all of its consumers in the schedule, so its backward runs after that.
+        shared = MULTI_BN_BWD and self.record and train and len(segs) > 1
+        if shared:
+            for sg in segs:
+                self.bn_shared.setdefault(id(sg), {"act": sg, "left": 0, "items": []})["left"] += 1
         if self.record:
             def bwd():
+                if shared:
+                    sums = torch.zeros((2, ctot), dtype=torch.float32, device=dev) if y.g is None else \
+                        torch.empty((2, ctot), dtype=torch.float32, device=dev)
+                    self.grads[prefix + ".weight"], self.grads[prefix + ".bias"] = sums[1], sums[0]
+                    c0, ready = 0, []
+                    for sg, st in zip(segs, stats):
+                        Cc = sg.t.shape[3]
+                        ent = self.bn_shared[id(sg)]
+                        if y.g is not None:
+                            ent["items"].append((y.g[..., c0:c0 + Cc], g[c0:c0 + Cc], b[c0:c0 + Cc], sums[0, c0:c0 + Cc], sums[1, c0:c0 + Cc],
+                                                 float(eps), bool(relu), st, prefix))
+                        ent["left"] -= 1
+                        if ent["left"] == 0 or len(ent["items"]) == _lib.BN_MAX_MULTI:
+                            ready.append(ent)
+                        c0 += Cc
+                    self._flush_shared_bn(ready)
+                    return
                 if y.g is None:
                     return
                 accs = []
@@ -453,6 +482,28 @@ class DecoderRun:
                         ops.act_bwd(y2.g, y2.t, ACT_RELU, out=y.g, accumulate=True)
                 self.tape.append(bwd2)
         return (y, y2) if relu_copy else y
+
+    def _flush_shared_bn(self, ready):
+        """Backward of the input tensors whose concatenation BatchNorms have all contributed: tensors that were normalised by the SAME
+        BatchNorms (same count, eps, ReLU) share one bts_bn_bwd_multi launch (up to three tensors; it reads each once per pass for all
+        of its BatchNorms and writes its gradient once)."""
+        groups = {}
+        for ent in ready:
+            items, ent["items"] = ent["items"], []
+            if not items:
+                continue
+            sg = ent["act"]
+            for key in sorted({(it[5], it[6]) for it in items}):
+                group = [it for it in items if (it[5], it[6]) == key]
+                acc = sg.g is not None
+                if not acc:
+                    sg.g = torch.empty(sg.t.shape, dtype=self.dtype, device=sg.t.device)
+                mean, var = group[0][7]
+                tag = "+".join(it[8].split(".")[0] for it in group)
+                groups.setdefault((key, len(group), tag), []).append((sg.t, mean, var, sg.g, acc, [it[:5] for it in group]))
+        for ((eps, relu), n, tag), tensors in groups.items():
+            for i in range(0, len(tensors), _lib.BN_MULTI_TENSORS):
+                ops.bn_bwd_multi(tensors[i:i + _lib.BN_MULTI_TENSORS], eps, relu, True, tag=tag)
 
     def relu(self, x):
         self._use(x, False)
@@ -643,6 +694,8 @@ class DecoderRun:
             for fn in reversed(self.tape):
                 fn()
             self._flush_wgrads()
+            if any(e["items"] or e["left"] for e in self.bn_shared.values()):
+                raise BtsAmdError("a concatenation BatchNorm's backward was left pending at the end of the pass")
         finally:
             # an error mid-pass must not leave (layer, inputs, dz, slot-of-THIS-arena) tuples behind for a retried backward to flush
             self.wgrad_pending = []

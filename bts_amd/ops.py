@@ -406,6 +406,49 @@ def bn_bwd_ms(dy, xs, dxs, accs, stats, gamma, beta, eps, relu, use_batch_stats,
     return sums[0], sums[1]
 
 
+def bn_bwd_multi(tensors, eps, relu, use_batch_stats, tag=None):
+    """Backward of SEVERAL BatchNorm(+ReLU) layers that all normalised the same tensors (the dense-ASPP first_bn layers,
+    bts.py:51-66, 211-218) in one reduction + one apply pass: dx (+)= the sum of their input gradients.
+    tensors: list (<= 3) of (x, mean, var, dx, accumulate, contribs) over the same pixels, every one with the SAME number (<= 4) of
+    contribs = (dy, gamma, beta, dbeta, dgamma): dy = the NHWC channel SLICE [.., c0:c0+C] of that BatchNorm's output gradient,
+    gamma / beta / dbeta / dgamma = the same channel range of its f32 parameter / gradient arrays (dbeta, dgamma are written)."""
+    nt = len(tensors)
+    if not 1 <= nt <= _lib.BN_MULTI_TENSORS:
+        raise BtsAmdError("bn_bwd_multi: 1..%d tensors per launch" % _lib.BN_MULTI_TENSORS)
+    x0 = tensors[0][0]
+    n = len(tensors[0][5])
+    if not 1 <= n <= _lib.BN_MAX_MULTI:
+        raise BtsAmdError("bn_bwd_multi: 1..%d BatchNorms per launch" % _lib.BN_MAX_MULTI)
+    _lib.require_gpu(x0)
+    d = _lib.BnMultiDesc()
+    d.dtype, d.n, d.nt, d.relu, d.M = dtype_code(x0.dtype), n, nt, int(bool(relu)), npix(x0)
+    d.eps, d.use_batch_stats = float(eps), int(bool(use_batch_stats))
+    passes = 0
+    for ti, (x, mean, var, dx, accumulate, contribs) in enumerate(tensors):
+        if len(contribs) != n or x.dtype != x0.dtype or npix(x) != npix(x0) or dx.dtype != x.dtype or tuple(dx.shape) != tuple(x.shape):
+            raise BtsAmdError("bn_bwd_multi: tensors of one launch share dtype, pixels and the number of BatchNorms")
+        for t in (mean, var):
+            if t.dtype != torch.float32 or t.numel() != x.shape[3] or not t.is_contiguous():
+                raise BtsAmdError("bn_bwd_multi: statistics must be contiguous f32 [%d]" % x.shape[3])
+        T = d.t[ti]
+        T.x, T.x_stride, T.C = x.data_ptr(), pix_stride(x), x.shape[3]
+        T.mean, T.var = mean.data_ptr(), var.data_ptr()
+        T.dx, T.dx_stride, T.accumulate = dx.data_ptr(), pix_stride(dx), int(bool(accumulate))
+        for i, (dy, g, b, db, dg) in enumerate(contribs):
+            if dy.dtype != x.dtype or tuple(dy.shape) != tuple(x.shape):
+                raise BtsAmdError("bn_bwd_multi: gradient slice %s %s does not match x %s %s" % (tuple(dy.shape), dy.dtype, tuple(x.shape), x.dtype))
+            for t in (g, b, db, dg):
+                if t.dtype != torch.float32 or t.numel() != x.shape[3] or not t.is_contiguous():
+                    raise BtsAmdError("bn_bwd_multi: per-channel arrays must be contiguous f32 [%d]" % x.shape[3])
+            T.c[i].dy, T.c[i].dy_stride = dy.data_ptr(), pix_stride(dy)
+            T.c[i].gamma, T.c[i].beta, T.c[i].dbeta, T.c[i].dgamma = g.data_ptr(), b.data_ptr(), db.data_ptr(), dg.data_ptr()
+        passes += x.shape[3] * (2 * (1 + n) + (2 if accumulate else 1))
+    ws = torch.empty(call("bts_bn_bwd_multi_workspace_bytes", C.byref(d)) // 4, dtype=torch.float32, device=x0.device)
+    if profiler.ACTIVE is not None:      # reduction: x + n dy; apply: x + n dy read, dx written (+ read when accumulating)
+        profiler.note("bn_bwd_multi", "hbm", npix(x0) * x0.element_size() * passes, tag)
+    call("bts_bn_bwd_multi", C.byref(d), _p(ws), stream_ptr())
+
+
 def act_bwd(dy, y, act, out=None, out_dtype=None, out_channels=None, y_scale=1.0, y_scale_n=None, accumulate=False):
     """dz (+)= dy * act'(y).  dy/y may be NHWC [N,H,W,C] or single-channel maps [N,H,W]."""
     if dy.dim() == 3:

@@ -405,6 +405,40 @@ typedef struct {
 int bts_bn_apply(const bts_bn_desc_t* d, bts_stream_t stream);
 long bts_bn_bwd_workspace_bytes(const bts_bn_desc_t* d);
 int bts_bn_bwd(const bts_bn_desc_t* d, void* workspace, float* sums, bts_stream_t stream);
+/* SEVERAL BatchNorm(+ReLU) layers over SHARED input tensors, backward (bts.py:51-66 + 211-218: the dense-ASPP `first_bn` of
+ * daspp_6 / 12 / 18 / 24 each normalise cat(up3, skip, daspp_3, ...) -- the same tensors, the same batch statistics, another
+ * gamma / beta each time; under autograd every one of them walks the shared prefix twice and read-modify-writes its gradient).
+ * For every input tensor x_t (statistics mean_t / var_t; t < nt <= BTS_BN_MULTI_TENSORS, all of M pixels) and the n <=
+ * BTS_BN_MAX_MULTI BatchNorms b that all saw it:
+ *     dz_b = dy_b * (relu ? (xhat * gamma_b + beta_b > 0) : 1),   xhat = (x - mean) / sqrt(var + eps)
+ *     dbeta_b[c] = sum dz_b,  dgamma_b[c] = sum dz_b * xhat                               (written, not accumulated)
+ *     dx (+)= sum_b gamma_b / sqrt(var + eps) * (dz_b - (use_batch_stats ? dbeta_b / M + xhat * dgamma_b / M : 0))
+ * -- bts_bn_bwd's arithmetic per BatchNorm, with x read once per pass for all of them and dx written once: 2 (1 + n) + 1 (+ 1 when
+ * accumulating) tensor passes instead of n x (5 or 6), one reduction + one final + one apply launch for all nt tensors.  dy_b /
+ * gamma_b / beta_b / dbeta_b / dgamma_b point AT the tensor's first channel inside BatchNorm b's arrays (its channel range of the
+ * concatenation).  workspace >= bts_bn_bwd_multi_workspace_bytes(d), 16-byte aligned; no atomics: the sums are order-deterministic. */
+#define BTS_BN_MAX_MULTI 4
+#define BTS_BN_MULTI_TENSORS 3
+typedef struct {
+    const void* dy;  int32_t dy_stride;             /* gradient of BatchNorm b's output, NHWC, at x's first channel */
+    const float* gamma; const float* beta;          /* [C] */
+    float* dbeta; float* dgamma;                    /* [C] outputs */
+} bts_bn_contrib_t;
+typedef struct {
+    const void* x; int32_t x_stride, C;
+    const float* mean; const float* var;            /* [C] */
+    void* dx; int32_t dx_stride, accumulate;
+    bts_bn_contrib_t c[BTS_BN_MAX_MULTI];
+} bts_bn_multi_tensor_t;
+typedef struct {
+    int32_t dtype, n, nt, relu;
+    int64_t M;                                      /* pixels */
+    float eps;
+    int32_t use_batch_stats;
+    bts_bn_multi_tensor_t t[BTS_BN_MULTI_TENSORS];
+} bts_bn_multi_desc_t;
+long bts_bn_bwd_multi_workspace_bytes(const bts_bn_multi_desc_t* d);
+int bts_bn_bwd_multi(const bts_bn_multi_desc_t* d, void* workspace, bts_stream_t stream);
 /* dz (+)= dy * act'(y) given the activation OUTPUT y (ELU: y>0 ? 1 : y+1; SIGMOID: y(1-y); RELU: y>0).  accumulate: only for the
  * vector form (same dtype everywhere, ELU / RELU, 16-byte aligned channel vectors), dz != dy. */
 int bts_act_bwd(const void* dy, int dy_dtype, int dy_stride, const void* y, int y_dtype, int y_stride,

@@ -732,6 +732,143 @@ def test_batchnorm_concat_multi_segment(dt, case, train):
     assert rel(dg, gr.grad) < (5e-4 if not (bf and (fold or copy)) else 1e-2) and rel(db, br.grad) < (5e-4 if not (bf and copy) else 1e-2)
 
 
+def _clear_relu_borderline(gy, x, g, b, rm, rv, train, eps, c0):
+    """Zero gy[:, c0:c0+C] where the BatchNorm output (f64 evaluation) is within 1e-5 of the ReLU threshold: two correct f32
+    evaluations of y may take different branches there -- ONE such element (y = 1.7e-9 in f64, -1.4e-8 in torch's CPU kernel,
+    gradient 1.6) moved dbeta of a 2 494-pixel channel by 8 % in the first run of the test below."""
+    xd = x.double()
+    m = xd.mean((0, 2, 3)) if train else rm.double()
+    v = xd.var((0, 2, 3), unbiased=False) if train else rv.double()
+    y = (xd - m[None, :, None, None]) / torch.sqrt(v + eps)[None, :, None, None] * g.double()[None, :, None, None] + b.double()[None, :, None, None]
+    C = x.shape[1]
+    gy[:, c0:c0 + C][y.abs() < 1e-5] = 0.0
+    return gy
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+@pytest.mark.parametrize("relu,acc,train", [(True, False, True), (True, True, True), (False, False, True), (True, True, False)],
+                         ids=["relu", "relu_acc", "plain", "relu_acc_eval"])
+def test_batchnorm_shared_input_multi_backward(dt, n, relu, acc, train):
+    """bts_bn_bwd_multi: n BatchNorm(+ReLU) layers that normalise the SAME tensor with the same batch statistics and their own
+    gamma / beta (the dense-ASPP first_bn layers all see cat(up4, skip2, daspp_3, ...), bts.py:51-66 + 211-218), backward in one
+    reduction + one apply pass, against F.batch_norm autograd of the n layers on CPU f32: the summed input gradient (written or
+    accumulated), every dgamma / dbeta.  The output gradients are channel SLICES of wider tensors, as in the decoder."""
+    from bts_amd import ops
+    gen = torch.Generator().manual_seed(31 + n)
+    v = 4 if dt == torch.float32 else 8
+    bf = dt == torch.bfloat16
+    N, H, W, Cc, eps = 2, 29, 43, 40, 1.1e-5
+    x = torch.randn(N, Cc, H, W, generator=gen) * 1.5 + 0.3
+    if bf:
+        x = x.to(dt).float()
+    xr = x.clone().requires_grad_(True)
+    gs = [(torch.rand(Cc, generator=gen) + 0.5) for _ in range(n)]
+    bs_ = [(torch.rand(Cc, generator=gen) - 0.5) for _ in range(n)]
+    rm, rv = torch.rand(Cc, generator=gen) - 0.5, torch.rand(Cc, generator=gen) + 0.5
+    grs = [g.clone().requires_grad_(True) for g in gs]
+    brs = [b.clone().requires_grad_(True) for b in bs_]
+    wide = [Cc + 8 * (i + 1) for i in range(n)]          # BatchNorm i's concatenation is wider; x sits at channel offset 8
+    gys, obj = [], 0.0
+    for i in range(n):
+        y = F.batch_norm(xr, rm.clone(), rv.clone(), grs[i], brs[i], train, 0.01, eps)
+        if relu:
+            y = F.relu(y)
+        gy = torch.randn(N, wide[i], H, W, generator=gen)
+        if bf:
+            gy = gy.to(dt).float()
+        if relu:
+            gy = _clear_relu_borderline(gy, x, gs[i], bs_[i], rm, rv, train, eps, 8)
+        gys.append(gy)
+        obj = obj + (y * gy[:, 8:8 + Cc]).sum()
+    obj.backward()
+    xt = _nhwc(x, dt, v)
+    if train:
+        mean, var = ops.bn_stats(xt)
+    else:
+        mean, var = rm.to(DEV), rv.to(DEV)
+    base = torch.randn(xt.shape, generator=gen).to(dt).to(DEV)
+    dx = base.clone() if acc else torch.empty_like(xt)
+    contribs, keep, dyws = [], [], []
+    for i in range(n):
+        dyw = _nhwc(gys[i], dt, v)
+        gw, bw = torch.zeros(wide[i], device=DEV), torch.zeros(wide[i], device=DEV)
+        gw[8:8 + Cc], bw[8:8 + Cc] = gs[i].to(DEV), bs_[i].to(DEV)
+        sums = torch.full((2, wide[i]), float("nan"), device=DEV)
+        keep.append(sums)
+        dyws.append(dyw)
+        contribs.append((dyw[..., 8:8 + Cc], gw[8:8 + Cc], bw[8:8 + Cc], sums[0, 8:8 + Cc], sums[1, 8:8 + Cc]))
+    # a second tensor in the same launch (the n = 4 group of the decoder has three: up3, skip, daspp_3): 24 channels -- another lane
+    # width than the first one alone would take --, accumulating iff the first does not, its own statistics and parameter slices
+    gen2 = torch.Generator().manual_seed(131 + n)
+    C2 = 24
+    x2 = torch.randn(N, C2, H, W, generator=gen2) * 0.7 - 0.2
+    if bf:
+        x2 = x2.to(dt).float()
+    x2r = x2.clone().requires_grad_(True)
+    g2 = [(torch.rand(C2, generator=gen2) + 0.5) for _ in range(n)]
+    b2 = [(torch.rand(C2, generator=gen2) - 0.5) for _ in range(n)]
+    rm2, rv2 = torch.rand(C2, generator=gen2) - 0.5, torch.rand(C2, generator=gen2) + 0.5
+    g2r = [g.clone().requires_grad_(True) for g in g2]
+    b2r = [b.clone().requires_grad_(True) for b in b2]
+    gy2, obj2 = [], 0.0
+    for i in range(n):
+        y2 = F.batch_norm(x2r, rm2.clone(), rv2.clone(), g2r[i], b2r[i], train, 0.01, eps)
+        if relu:
+            y2 = F.relu(y2)
+        t = torch.randn(N, C2, H, W, generator=gen2)
+        if bf:
+            t = t.to(dt).float()
+        if relu:
+            t = _clear_relu_borderline(t, x2, g2[i], b2[i], rm2, rv2, train, eps, 0)
+        gy2.append(t)
+        obj2 = obj2 + (y2 * t).sum()
+    obj2.backward()
+    x2t = _nhwc(x2, dt, v)
+    mean2, var2 = ops.bn_stats(x2t) if train else (rm2.to(DEV), rv2.to(DEV))
+    base2 = torch.randn(x2t.shape, generator=gen2).to(dt).to(DEV)
+    dx2t = base2.clone() if not acc else torch.empty_like(x2t)
+    sums2 = [torch.full((2, C2), float("nan"), device=DEV) for _ in range(n)]
+    contribs2 = [(_nhwc(gy2[i], dt, v), g2[i].to(DEV), b2[i].to(DEV), sums2[i][0], sums2[i][1]) for i in range(n)]
+    ops.bn_bwd_multi([(xt, mean, var, dx, acc, contribs), (x2t, mean2, var2, dx2t, not acc, contribs2)], eps, relu, train)
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert rel(sums2[i][1], g2r[i].grad) < 5e-4 and rel(sums2[i][0], b2r[i].grad) < 5e-4, ("second tensor", i)
+    want2 = x2r.grad + (base2.float().permute(0, 3, 1, 2).cpu() if not acc else 0.0)
+    got2 = dx2t.float().permute(0, 3, 1, 2)
+    if bf:
+        assert bf16_bad(got2, want2) <= 3 * n, bf16_excess(got2, want2)
+    else:
+        assert rel(got2, want2) < 1e-4 * (10 if not acc else 5)
+    def device_sums(i):      # the kernel's own arithmetic with torch ops on the device (diagnostic for a failing comparison)
+        xh = (xt.float() - mean) * torch.rsqrt(var + eps)
+        d = dyws[i][..., 8:8 + Cc].float()
+        if relu:
+            d = torch.where(xh * gs[i].to(DEV) + bs_[i].to(DEV) > 0, d, torch.zeros_like(d))
+        return d.sum((0, 1, 2)).cpu(), (d * xh).sum((0, 1, 2)).cpu()
+    for i in range(n):      # the statistics first: a wrong sum shows up here before it does in dx
+        eg, eb = rel(keep[i][1, 8:8 + Cc], grs[i].grad), rel(keep[i][0, 8:8 + Cc], brs[i].grad)
+        if not (eg < 5e-4 and eb < 5e-4):
+            db_dev, dg_dev = device_sums(i)
+            worst = int((keep[i][0, 8:8 + Cc].cpu() - brs[i].grad).abs().argmax())
+            raise AssertionError("BatchNorm %d: dgamma %.3g dbeta %.3g; worst channel %d: kernel %.6f, device torch %.6f, cpu autograd %.6f; "
+                                 "beta %.6f gamma %.6f" % (i, eg, eb, worst, keep[i][0, 8 + worst].item(), db_dev[worst].item(),
+                                                          brs[i].grad[worst].item(), bs_[i][worst].item(), gs[i][worst].item()))
+        assert torch.isnan(keep[i][:, :8]).all() and torch.isnan(keep[i][:, 8 + Cc:]).all()      # nothing outside the channel range
+    want = xr.grad + (base.float().permute(0, 3, 1, 2).cpu() if acc else 0.0)
+    got = dx.float().permute(0, 3, 1, 2)
+    if bf:
+        assert bf16_bad(got, want) <= 3 * n, bf16_excess(got, want)
+    else:
+        assert rel(got, want) < 1e-4 * (10 if acc else 5)
+    # the same through one bts_bn_bwd per BatchNorm (the rounds 3-5 form): the two product paths agree to f32 summation order
+    if train and not bf:
+        dx2 = base.clone() if acc else torch.zeros_like(xt)
+        for i in range(n):
+            ops.bn_bwd_ms(dyws[i][..., 8:8 + Cc], [xt], [dx2], [True], [(mean, var)], gs[i].to(DEV), bs_[i].to(DEV), eps, relu, True)
+        assert rel(dx.float(), dx2.float()) < 2e-5
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_act_bwd_accumulate(dt):
     from bts_amd import ops

@@ -178,6 +178,38 @@ def test_fused_train_chain_matches_layerwise(nf, feat, monkeypatch):
         assert rel(a, b) < 6e-2
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 5e-5), (torch.bfloat16, 6e-2)])
+def test_shared_input_bn_backward_matches_per_layer(dt, tol, monkeypatch):
+    """The dense-ASPP first_bn layers (bts.py:51-66, 211-218) each normalise a prefix of the same concatenation; the decoder hands
+    the backward of every shared tensor to one bts_bn_bwd_multi launch per tensor (decoder.MULTI_BN_BWD).  Outputs and every
+    gradient must agree with the rounds 3-5 schedule (one bts_bn_bwd per BatchNorm), and the new launches really ran."""
+    from bts_amd import decoder as decoder_mod, profiler
+    feat, nf, B, H, W = [16, 16, 32, 48, 80], 256, 2, 64, 96
+    gen = torch.Generator().manual_seed(47)
+    P = O.make_decoder_params(feat, nf, gen, randomize_bn=True)
+    feats = O.make_features(feat, B, H, W, gen)
+    focal = O.synth_focal(B, "kitti")
+    gt = O.synth_depth_gt(B, H, W, "kitti", gen)
+    res = {}
+    for multi in (True, False):
+        monkeypatch.setattr(decoder_mod, "MULTI_BN_BWD", multi)
+        dec, _ = build(feat, nf, "kitti", P, dtype=dt)
+        prof = profiler.enable()
+        fs, outs, loss, aux = run(dec, feats, focal, gt, "kitti")
+        names = [r[0] for r in prof.records]
+        profiler.disable()
+        assert (names.count("bn_bwd_multi") > 0) == multi, names
+        res[multi] = ([o.detach() for o in outs], {n: p.grad for n, p in dec.named_parameters()}, [f.grad for f in fs],
+                      names.count("bn_bwd") + names.count("bn_bwd_multi"))
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)              # the forward pass is the same launches
+    worst = {n: rel(g, res[False][1][n]) for n, g in res[True][1].items()}
+    assert max(worst.values()) < tol, sorted(worst.items(), key=lambda kv: -kv[1])[:6]
+    for a, b in zip(res[True][2], res[False][2]):
+        assert rel(a, b) < tol
+    print("bn backward launches: multi %d, per layer %d" % (res[True][3], res[False][3]))
+
+
 @pytest.mark.parametrize("B,H,W", [(1, 96, 160), (3, 32, 64), (1, 416, 544)])
 def test_decoder_ragged_shapes_vs_oracle(B, H, W):
     """Odd grid sizes (H/32 x W/32 = 3x5, 1x2, 13x17 = BASELINE configs[0/1] 416x544), batch sizes that are not powers of
