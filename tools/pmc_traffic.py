@@ -44,6 +44,8 @@ def family(name):
         return "conv_halo_wide<bf16,%dx256>" % (int(m.group(1)) * 32)
     if n.startswith("conv_halo_wide"):
         return "conv_halo_wide<bf16,128x256>"
+    if n.startswith("conv_wgrad_halo_tr_up"):
+        return "conv_wgrad_halo_tr_up<bf16>"
     if n.startswith("conv_wgrad_halo_tr"):
         return "conv_wgrad_halo_tr<bf16>"
     if n.startswith("conv_c1_fwd"):
@@ -54,6 +56,8 @@ def family(name):
         return "conv_c1_wgrad"
     if n.startswith("conv_wgrad_c1"):
         return "conv_wgrad_c1<bf16>"
+    if n.startswith("bn_bwd_multi_"):
+        return "bn_bwd_multi"
     if n.startswith("bn_bwd_"):
         return "bn_bwd"
     if n.startswith("bn_apply_ms"):
@@ -75,7 +79,7 @@ def family(name):
 
 # families whose C-ABI call is several kernels: the CALL count is the dispatch count of one marker kernel (the counter bytes of all of
 # the family's kernels are summed and divided by it, so the figure compares with bench.py's per-call algorithmic bytes)
-CALL_MARKER = {"bn_bwd": "bn_bwd_apply", "bn_stats": "bn_stats_partial"}
+CALL_MARKER = {"bn_bwd": "bn_bwd_apply", "bn_bwd_multi": "bn_bwd_multi_apply", "bn_stats": "bn_stats_partial"}
 
 
 def load(path, counter):
