@@ -53,10 +53,23 @@ def encoder_environment():
         os.environ["PYTORCH_MIOPEN_SUGGEST_NHWC"] = nhwc
         os.environ["PYTORCH_MIOPEN_SUGGEST_NHWC_BATCHNORM"] = nhwc
     db = _flag("--miopen-db", os.path.join(ROOT, "bts_amd", "miopen_db"))
+    mode = _flag("--miopen-find-mode", "fast")
     if db and db != "none":
         os.makedirs(db, exist_ok=True)
-        os.environ["MIOPEN_USER_DB_PATH"] = db
-    mode = _flag("--miopen-find-mode", "fast")
+        use = db
+        if mode != "normal":
+            # Every process reads the recorded results from its OWN copy: MIOpen appends to the user db while it runs (86 of the encoder's
+            # problems are re-recorded by every run), and the ranks of an N > 1 run would all append to the same files at the same moment.
+            # (Find mode `normal` -- tools/miopen_warm.sh recording the results -- writes into the directory itself.)
+            import atexit
+            import shutil
+            import tempfile
+            use = tempfile.mkdtemp(prefix="bts_miopen_db_")
+            for f in os.listdir(db):
+                if f.endswith(".txt"):
+                    shutil.copy2(os.path.join(db, f), os.path.join(use, f))
+            atexit.register(shutil.rmtree, use, True)
+        os.environ["MIOPEN_USER_DB_PATH"] = use
     if mode != "default":
         os.environ["MIOPEN_FIND_MODE"] = {"normal": "1", "fast": "2", "hybrid": "3", "dynamic_hybrid": "5"}[mode]
 

@@ -147,7 +147,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
                 dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
-                if not (dense and p.grad.stride() == p.stride() and p.dtype == torch.float32 and p.grad.dtype == torch.float32):
+                same = all(a == b for a, b, n in zip(p.grad.stride(), p.stride(), p.shape) if n != 1)     # (a size-1 dimension's stride is free)
+                if not (dense and same and p.dtype == torch.float32 and p.grad.dtype == torch.float32):
                     raise RuntimeError("FusedAdamW needs dense f32 parameters with identically laid out gradients")
             t = self._table(gi, plist)
             b1, b2 = g["betas"]

@@ -34,6 +34,22 @@ import torch
 import torch.distributed as dist
 
 
+def _grad_view(flat, off, p):
+    """The slice [off, off + p.numel()) of a flat bucket as a gradient laid out LIKE THE PARAMETER: the same strides over the
+    bucket's storage.  A contiguous view under a channels-last parameter (the stock encoder in torch.channels_last, round 6) is a
+    layout autograd has to convert into on every accumulation and the fused optimizer refuses (it walks parameter and gradient with
+    one index)."""
+    # dense in some dimension order (what .to(memory_format=...) produces): sorted by stride, every stride is the product of the
+    # sizes behind it
+    dims = sorted(range(p.dim()), key=lambda d: (p.stride(d), -p.size(d)), reverse=True)
+    expect = 1
+    for d in reversed(dims):
+        if p.size(d) != 1 and p.stride(d) != expect:
+            raise ValueError("GradAllReducer: parameter of shape %s with strides %s is not dense" % (tuple(p.shape), p.stride()))
+        expect *= p.size(d)
+    return torch.as_strided(flat, p.size(), p.stride(), off)
+
+
 class GradAllReducer:
     def __init__(self, params, bucket_bytes=64 << 20, process_group=None, reduce_single=False, tail_bytes=8 << 20):
         self.group = process_group
@@ -78,7 +94,7 @@ class GradAllReducer:
             flat = torch.zeros(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
             off = 0
             for p in ps:
-                p.grad = flat[off:off + p.numel()].view_as(p)      # autograd accumulates into the bucket
+                p.grad = _grad_view(flat, off, p)                  # autograd accumulates into the bucket
                 off += p.numel()
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
             self.buckets.append((flat, ps))

@@ -32,7 +32,7 @@ class Net(nn.Module):
         return self.dec(self.enc(x))
 
 
-def _worker(rank, world, port, bucket_bytes, q):
+def _worker(rank, world, port, bucket_bytes, channels_last, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -43,7 +43,13 @@ def _worker(rank, world, port, bucket_bytes, q):
         broadcast_parameters(net)
         ref = Net()
         ref.load_state_dict(net.state_dict())
+        if channels_last:      # bench.py runs the stock encoder in torch.channels_last (round 6): the bucket views must follow the parameters' strides
+            net.enc.to(memory_format=torch.channels_last)
+            assert not net.enc[0].weight.is_contiguous()
         red = GradAllReducer(net.parameters(), bucket_bytes=bucket_bytes)
+        for n_, p_ in net.named_parameters():
+            if p_.requires_grad:
+                assert all(a == b for a, b, k in zip(p_.grad.stride(), p_.stride(), p_.shape) if k != 1), (n_, p_.grad.stride(), p_.stride())
         assert len(red.buckets) >= (2 if bucket_bytes < 1000 else 1)
         x = torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(rank))   # rank-local batch
         for it in range(2):                       # two steps: buckets are reused, zero_grad keeps the views
@@ -128,13 +134,14 @@ def _worker(rank, world, port, bucket_bytes, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("channels_last", [False, True], ids=["contiguous", "channels_last"])
 @pytest.mark.parametrize("bucket_bytes", [512, 64 << 20])
-def test_grad_allreducer_world2_gloo(bucket_bytes):
+def test_grad_allreducer_world2_gloo(bucket_bytes, channels_last):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, bucket_bytes, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bucket_bytes, channels_last, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]

@@ -82,3 +82,10 @@ gzip -9 -f $O/${T}_pmc_FETCH_SIZE.csv $O/${T}_pmc_WRITE_SIZE.csv $O/${T}_pmc_sq.
 ls -la $O | grep ${T}_ | head -40
 du -sh $O
 echo "done t=$(( $(date +%s) - T0 ))"
+# 6. the N > 1 code path on this one GPU: world size 1 over RCCL (flat parameter broadcast, hook-driven GradAllReducer, BufferSync, eager step) and
+#    two self-spawned ranks over gloo sharing the GPU (plumbing evidence, not a scaling number)
+step 200 python bench.py --force-dist 1 --backend nccl --steps 10 --warmup 3 --no-cpu-baseline --parity 0 --lpg-op 0 --f32-line 0 > $O/${T}_bench_world1_rccl.json 2> $O/${T}_bench_world1_rccl.err
+cut -c1-200 $O/${T}_bench_world1_rccl.json
+step 300 python bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 --no-cpu-baseline --parity 0 --lpg-op 0 --f32-line 0 > $O/${T}_bench_selfspawn_2ranks_one_gpu_gloo.json 2> $O/${T}_bench_selfspawn_2ranks_one_gpu_gloo.err
+cut -c1-200 $O/${T}_bench_selfspawn_2ranks_one_gpu_gloo.json
+echo "dist t=$(( $(date +%s) - T0 ))"
