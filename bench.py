@@ -51,7 +51,9 @@ def encoder_environment():
     nhwc = _flag("--miopen-nhwc", "1")
     if nhwc in ("0", "1"):
         os.environ["PYTORCH_MIOPEN_SUGGEST_NHWC"] = nhwc
-        os.environ["PYTORCH_MIOPEN_SUGGEST_NHWC_BATCHNORM"] = nhwc
+        # BatchNorm separately (--miopen-nhwc-bn, default = the convolutions' setting): with 0 ATen does not hand channels-last BatchNorm
+        # inputs to MIOpen at all and runs its own channels-last kernels
+        os.environ["PYTORCH_MIOPEN_SUGGEST_NHWC_BATCHNORM"] = _flag("--miopen-nhwc-bn", nhwc)
     db = _flag("--miopen-db", os.path.join(ROOT, "bts_amd", "miopen_db"))
     mode = _flag("--miopen-find-mode", "fast")
     if db and db != "none":
@@ -102,6 +104,8 @@ def parse():
                     "the recorded find results, profiles/r06_ab_encoder_layout.json)")
     ap.add_argument("--miopen-nhwc", type=int, default=1, help="1 / 0: export PYTORCH_MIOPEN_SUGGEST_NHWC(+_BATCHNORM) = 1 / 0 before the first "
                     "convolution (without it PyTorch-ROCm hands MIOpen NCHW copies of channels-last tensors); -1: leave the environment alone")
+    ap.add_argument("--miopen-nhwc-bn", type=int, default=None, help="PYTORCH_MIOPEN_SUGGEST_NHWC_BATCHNORM (default: as --miopen-nhwc); 0 = ATen's "
+                    "own channels-last BatchNorm kernels instead of MIOpen's")
     ap.add_argument("--miopen-db", default=os.path.join(ROOT, "bts_amd", "miopen_db"), help="MIOPEN_USER_DB_PATH: directory of the recorded "
                     "MIOpen find results (tools/miopen_warm.sh writes it); 'none' = MIOpen's own default")
     ap.add_argument("--miopen-find-mode", default="fast", choices=["fast", "normal", "hybrid", "dynamic_hybrid", "default"],
@@ -256,7 +260,8 @@ def f32_line_subprocess(args, parity, timeout_s=240):
     cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "f32", "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
            "--parity", "0", "--lpg-op", "0", "--f32-line", "0", "--eager-steps", "0", "--encoder", args.encoder, "--dataset", args.dataset,
            "--height", str(args.height), "--width", str(args.width), "--batch", str(args.batch),
-           "--channels-last", str(args.channels_last), "--miopen-nhwc", str(args.miopen_nhwc), "--miopen-db", args.miopen_db,
+           "--channels-last", str(args.channels_last), "--miopen-nhwc", str(args.miopen_nhwc),
+           "--miopen-nhwc-bn", os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC_BATCHNORM", str(args.miopen_nhwc)), "--miopen-db", args.miopen_db,
            "--miopen-find-mode", args.miopen_find_mode, "--cudnn-benchmark", str(args.cudnn_benchmark)]
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
@@ -618,8 +623,8 @@ def infer_main(args):
            "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "%s no-grad forward, %dx%d, batch %d (BASELINE.json configs[4])" % (args.encoder, H, W, B),
-                      "encoder": "stock PyTorch-ROCm (%s, PYTORCH_MIOPEN_SUGGEST_NHWC=%s, cudnn.benchmark=%d, MIOPEN_FIND_MODE=%s, %s)" % (
-                          "channels_last" if args.channels_last else "contiguous NCHW", os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC", "unset"),
+                      "encoder": "stock PyTorch-ROCm (%s, PYTORCH_MIOPEN_SUGGEST_NHWC=%s (BatchNorm: %s), cudnn.benchmark=%d, MIOPEN_FIND_MODE=%s, %s)" % (
+                          "channels_last" if args.channels_last else "contiguous NCHW", os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC", "unset"), os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC_BATCHNORM", "unset"),
                           args.cudnn_benchmark, os.environ.get("MIOPEN_FIND_MODE", "unset"), miopen_db_note(args))}}
     if prof is not None:
         profiler.disable()
@@ -995,8 +1000,8 @@ def main():
                        (args.encoder, args.height, args.width, args.batch,
                         "kitti focal scaling" if args.dataset == "kitti" else "nyu (no focal scaling)"),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "grad_exchange": ("none" if not multi else ("torch DDP over %s" % args.backend if reducer is None else "bts GradAllReducer over %s" % args.backend)),
-                       "encoder": "stock PyTorch-ROCm (%s autocast, %s, PYTORCH_MIOPEN_SUGGEST_NHWC=%s, cudnn.benchmark=%d, MIOPEN_FIND_MODE=%s, %s)" % (
-                           args.dtype, "channels_last" if args.channels_last else "contiguous NCHW", os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC", "unset"),
+                       "encoder": "stock PyTorch-ROCm (%s autocast, %s, PYTORCH_MIOPEN_SUGGEST_NHWC=%s (BatchNorm: %s), cudnn.benchmark=%d, MIOPEN_FIND_MODE=%s, %s)" % (
+                           args.dtype, "channels_last" if args.channels_last else "contiguous NCHW", os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC", "unset"), os.environ.get("PYTORCH_MIOPEN_SUGGEST_NHWC_BATCHNORM", "unset"),
                            args.cudnn_benchmark, os.environ.get("MIOPEN_FIND_MODE", "unset"), miopen_db_note(args)), "decoder": "HIP kernels via libbts_amd.so", "launch": graph_note, "optimizer": "bts_adamw_step (fused HIP)" if own_opt else "torch.optim.AdamW(fused)",
                        "final_loss": round(final_loss, 5)},
         }
