@@ -208,6 +208,41 @@ def test_deferred_weight_gradients_group_in_arrival_order(monkeypatch):
     assert log == [("single", n) for n in names[:5]], log                      # the group of five fell back, layer by layer
 
 
+def test_shared_batchnorm_backward_groups_tensors_by_their_batchnorms(monkeypatch):
+    """DecoderRun._flush_shared_bn: input tensors that were normalised by the SAME BatchNorms leave in one bts_bn_bwd_multi launch
+    (three at most), a tensor with another set of BatchNorms in its own; a tensor whose gradient buffer exists accumulates, one
+    without gets a fresh buffer; entries without contributions launch nothing."""
+    from types import SimpleNamespace as NS
+
+    from bts_amd import decoder as dec
+    from bts_amd import ops
+    calls = []
+    monkeypatch.setattr(ops, "bn_bwd_multi", lambda tensors, eps, relu, ubs, tag=None: calls.append((tag, eps, relu, ubs, tensors)))
+    run = object.__new__(dec.DecoderRun)
+    run.dtype = torch.float32
+
+    def act(c, with_grad):
+        return NS(t=torch.zeros(1, 2, 2, c), g=torch.zeros(1, 2, 2, c) if with_grad else None)
+
+    def item(c, name, eps=1e-5, relu=True):
+        return (torch.zeros(1, 2, 2, c), torch.zeros(c), torch.zeros(c), torch.zeros(c), torch.zeros(c), eps, relu, (torch.zeros(c), torch.ones(c)), name)
+    four = ["daspp_24.first_bn", "daspp_18.first_bn", "daspp_12.first_bn", "daspp_6.first_bn"]
+    ents = []
+    for c, has_g in ((128, False), (192, False), (64, True), (32, False)):        # four tensors that saw all four BatchNorms
+        a = act(c, has_g)
+        ents.append({"act": a, "left": 0, "items": [item(c, n) for n in four]})
+    lone = {"act": act(64, True), "left": 0, "items": [item(64, n) for n in four[:3]]}        # another BatchNorm set
+    empty = {"act": act(8, False), "left": 0, "items": []}
+    run._flush_shared_bn(ents + [lone, empty])
+    assert [len(c[4]) for c in calls] == [3, 1, 1], [(c[0], len(c[4])) for c in calls]
+    assert calls[0][0] == calls[1][0] == "daspp_24+daspp_18+daspp_12+daspp_6" and calls[2][0] == "daspp_24+daspp_18+daspp_12"
+    accs = [t[4] for c in calls[:2] for t in c[4]]
+    assert accs == [False, False, True, False]
+    assert all(e["act"].g is not None and e["items"] == [] for e in ents + [lone]) and empty["act"].g is None
+    assert all(len(t[5]) == 4 for c in calls[:2] for t in c[4]) and len(calls[2][4][0][5]) == 3
+    assert all(c[1:4] == (1e-5, True, True) for c in calls)
+
+
 def test_bench_gpus_n_spawns_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher around it must start two ranks itself (the reference spawns its own:
     bts_main.py:600-602) and report the world it ran in; under a launcher whose world differs from --gpus it must refuse."""
