@@ -108,9 +108,14 @@ def test_reference_driver_loops_on_the_hip_path(tmp_path):
         # kernel for another batch size: allow one count on a handful of pixels, nothing more
         diff = np.abs(p.astype(np.int32) - want.astype(np.int32))
         assert diff.max() <= 1 and (diff > 0).mean() < 1e-2, (diff.max(), (diff > 0).mean())
-    pay1 = ref_loop.test_loop_device(bts_mod, targs, samples)          # batch 1, as the reference runs it: exact
+    # batch 1, as the reference runs it.  The uint16 kernel itself is bit-exact on a given f32 map (test_depth_to_uint16_bit_exact);
+    # here the map comes from a SECOND forward pass of a second model instance, and the stock encoder is not bit-reproducible across
+    # passes (MIOpen may have learnt another solver for a layer in between: this comparison was exact in two protocol runs of round 6
+    # and off by one count on a few pixels in the third) -- the same allowance as for the batched pass
+    pay1 = ref_loop.test_loop_device(bts_mod, targs, samples)
     for p, d in zip(pay1, preds[0]):
-        assert np.array_equal(p, (d * 256.0).astype(np.uint16))
+        diff = np.abs(p.astype(np.int32) - (d * 256.0).astype(np.uint16).astype(np.int32))
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-2, (diff.max(), (diff > 0).mean())
     # ---- online_eval (bts_main.py:250-319) on the device kernels against the reference-style host loop
     eargs = NS(**{**vars(targs), "min_depth_eval": 1e-3, "max_depth_eval": 80.0, "do_kb_crop": False, "garg_crop": True, "eigen_crop": False})
     model_e = ref_loop._load_for_test(bts_mod, targs)
